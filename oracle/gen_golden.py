@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Golden-vector generator -- TEST INFRASTRUCTURE, runs only in the build container.
+
+Imports the ONE hot-path module of the reference that is importable without TensorFlow,
+``LDPC_128/Ldpc_128_testing/fill_matrix_info.py`` (NumPy only), from /root/reference and
+records its outputs as small fixtures under tests/golden/:
+
+  code_<name>.npz       H, G, k for each code            (Code.load_code :70-129,
+                                                           Code.generator_matrix :44-69)
+  gf2elim_ccsds.npz     reliability-permuted copies of G  -> Code.gf2elim output + recorded
+                        column exchanges                  (Code.gf2elim :7-42, the routine
+                        that PB_OSD/pb_testing.py:231-266 ``full_gf2elim`` repeats verbatim)
+
+Only DATA is written (inputs and the reference's outputs); no reference source travels.
+The reference tree is imported with bytecode writing disabled so nothing is written there.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = "/root/reference/LDPC_128/Ldpc_128_testing"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+CODES = {
+    # fixture name -> alist (data files of the reference)
+    "ccsds_128_64": os.path.join(REF, "CCSDS_ldpc_n128_k64.alist"),
+    "array_121_60": os.path.join(REF, "ArrayCode_N121_K60_r0.50.alist"),
+    "ldpc_96_48": "/root/reference/LDPC_128/Ldpc_128_training/LDPC_N96_K48_P8_set0_dmin10.alist",
+}
+
+
+def main():
+    sys.path.insert(0, REF)
+    import fill_matrix_info as ref  # the reference's own module
+
+    os.makedirs(OUT, exist_ok=True)
+    codes = {}
+    for name, path in CODES.items():
+        with contextlib.redirect_stdout(io.StringIO()):
+            code = ref.Code(path)
+        codes[name] = code
+        np.savez_compressed(
+            os.path.join(OUT, f"code_{name}.npz"),
+            H=code.H.astype(np.uint8), G=code.G.astype(np.uint8), k=np.int64(code.k),
+            max_chk_degree=np.int64(code.max_chk_degree))
+        print(name, "H", code.H.shape, "G", code.G.shape, "k", code.k)
+
+    # ---- GE cases on the CCSDS code: G with columns in descending-|y| order ------------
+    code = codes["ccsds_128_64"]
+    G = code.G
+    k, n = G.shape
+    rng = np.random.default_rng(20241020)
+    cases = 384
+    ys = np.empty((cases, n), dtype=np.float32)
+    for i in range(cases):
+        snr = (1.0, 2.5, 3.5)[i % 3]
+        sigma = np.sqrt(1.0 / (2.0 * (k / n) * 10 ** (snr / 10)))
+        cw = rng.integers(0, 2, size=k).dot(G) % 2
+        ys[i] = np.where(cw == 0, 1, -1) * rng.normal(1.0, sigma, size=n)
+    # a few adversarial orders: long column-exchange chains
+    ys[-1] = np.linspace(2.0, 0.1, n)                       # identity order: parity part first
+    ys[-2] = np.linspace(0.1, 2.0, n)                       # reversed order
+    ys[-3] = np.concatenate([np.linspace(0.1, 1.0, 64), np.linspace(3.0, 2.0, 64)])
+    perms = np.argsort(-np.abs(ys), axis=1, kind="stable")
+    red = np.empty((cases, k, n), dtype=np.uint8)
+    swaps = np.full((cases, 64, 2), -1, dtype=np.int16)
+    nswaps = np.zeros(cases, dtype=np.int16)
+    for i in range(cases):
+        M, rec = code.gf2elim(np.copy(G[:, perms[i]]))
+        assert M.shape == (k, n)
+        red[i] = M
+        nswaps[i] = len(rec)
+        for t, (a, b) in enumerate(rec):
+            swaps[i, t] = (a, b)
+    np.savez_compressed(
+        os.path.join(OUT, "gf2elim_ccsds.npz"),
+        y=ys, perm=perms.astype(np.int16), reduced=np.packbits(red, axis=2),
+        swaps=swaps, nswaps=nswaps)
+    print("gf2elim cases", cases, "swaps mean %.2f max %d" % (nswaps.mean(), nswaps.max()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,455 @@
+/*
+ * ldpc_oracle.c -- TEST INFRASTRUCTURE ONLY (plain C restatement of the reference hot path).
+ *
+ * Not part of the product: nothing under short_ldpc_decoding_osd_amd/ links, loads or calls
+ * this file.  It is the checker used by tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py ("kind": "port", single thread).
+ *
+ * What it restates (file:line relative to /root/reference/LDPC_128/):
+ *   orc_gf2elim      PB_OSD/pb_testing.py:231-266  full_gf2elim
+ *                    (== Ldpc_128_testing/fill_matrix_info.py:7-42 Code.gf2elim; PINNED by
+ *                    tests/golden/gf2elim_ccsds.npz, produced by the reference's own module)
+ *   orc_generator    Ldpc_128_testing/fill_matrix_info.py:44-69 generator_matrix (PINNED by
+ *                    tests/golden/code_*.npz)
+ *   orc_nms          Ldpc_128_testing/ms_test.py:106-242 (NMS-1/2/3 flooding schedule)
+ *   orc_eval         Ldpc_128_testing/ms_test.py:36-54   get_eval
+ *   orc_osd_front    PB_OSD/pb_testing.py:268-320        swapped_info + identify_mrb
+ *   orc_tep_table    FS_OSD/convention_osd.py:13-47      generate_teps / query_boundary
+ *   orc_conv_osd     FS_OSD/convention_osd.py:49-76      convention_osd_main
+ *   orc_fs_osd       FS_OSD/fs_testing.py:22-64,129-161  fs_osd inner loop
+ *   orc_pb_osd       PB_OSD/pb_testing.py:35-41,100-149,366-500  pb_osd inner loop
+ *
+ * Parity status: the GF(2)/integer routines are pinned as noted.  Everything the reference
+ * runs through TensorFlow (float NMS, reduce_sum order, argsort ties, sigmoid/exp) is
+ * "parity unpinned": TensorFlow is absent from the build image and the reference ships no
+ * vectors; the float conventions chosen here are documented next to each routine and in
+ * DESIGN.md.  Build: make -C oracle   (gcc -O2 -ffp-contract=off; no -ffast-math).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_MAX_N 2048
+
+/* ------------------------------------------------------------------------------------ */
+/* GF(2) elimination with the reference's pivot rule, on an int32 matrix (row-major).    */
+/* Returns the number of rows left (all-zero rows are deleted as the reference does).     */
+/* swaps: pairs (j, col), *nswaps = count.                                                */
+/* ------------------------------------------------------------------------------------ */
+int orc_gf2elim(int32_t *M, int m, int n, int32_t *swaps, int32_t *nswaps)
+{
+    int i = 0, j = 0, ns = 0;
+    while (i < m && j < n) {
+        int r = -1;
+        for (int t = i; t < m; ++t)
+            if (M[(size_t)t * n + j]) { r = t; break; }
+        if (r >= 0) {
+            if (r != i)
+                for (int c = 0; c < n; ++c) {
+                    int32_t tmp = M[(size_t)r * n + c];
+                    M[(size_t)r * n + c] = M[(size_t)i * n + c];
+                    M[(size_t)i * n + c] = tmp;
+                }
+        } else {
+            int col = -1;
+            for (int c = j; c < n; ++c)
+                if (M[(size_t)i * n + c]) { col = c; break; }
+            if (col < 0) { /* redundant all-zero row: delete it, stay on (i, j) */
+                memmove(&M[(size_t)i * n], &M[(size_t)(i + 1) * n], sizeof(int32_t) * (size_t)(m - i - 1) * n);
+                --m;
+                continue;
+            }
+            for (int t = 0; t < m; ++t) {
+                int32_t tmp = M[(size_t)t * n + col];
+                M[(size_t)t * n + col] = M[(size_t)t * n + j];
+                M[(size_t)t * n + j] = tmp;
+            }
+            if (swaps) { swaps[2 * ns] = j; swaps[2 * ns + 1] = col; }
+            ++ns;
+        }
+        for (int t = 0; t < m; ++t) {
+            if (t == i || !M[(size_t)t * n + j]) continue;
+            for (int c = j; c < n; ++c) M[(size_t)t * n + c] ^= M[(size_t)i * n + c];
+        }
+        ++i; ++j;
+    }
+    if (nswaps) *nswaps = ns;
+    return m;
+}
+
+/* G = [H2^T | I] with the column exchanges undone in reverse order.  G must hold       */
+/* (n - rank) * n entries; returns k = n - rank, or -1 if H.G^T != 0.                    */
+int orc_generator(const int32_t *H, int m, int n, int32_t *G)
+{
+    int32_t *R = (int32_t *)malloc(sizeof(int32_t) * (size_t)m * n);
+    int32_t *sw = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n);
+    int32_t ns = 0;
+    memcpy(R, H, sizeof(int32_t) * (size_t)m * n);
+    int r = orc_gf2elim(R, m, n, sw, &ns);
+    int k = n - r;
+    for (int a = 0; a < k; ++a)
+        for (int c = 0; c < n; ++c)
+            G[(size_t)a * n + c] = (c < r) ? R[(size_t)c * n + (r + a)] : (c - r == a);
+    for (int s = ns - 1; s >= 0; --s) {
+        int x = sw[2 * s], y = sw[2 * s + 1];
+        for (int a = 0; a < k; ++a) {
+            int32_t tmp = G[(size_t)a * n + x];
+            G[(size_t)a * n + x] = G[(size_t)a * n + y];
+            G[(size_t)a * n + y] = tmp;
+        }
+    }
+    int bad = 0;
+    for (int c = 0; c < m && !bad; ++c)
+        for (int a = 0; a < k; ++a) {
+            int acc = 0;
+            for (int v = 0; v < n; ++v) acc ^= (H[(size_t)c * n + v] & G[(size_t)a * n + v]);
+            if (acc) { bad = 1; break; }
+        }
+    free(R); free(sw);
+    return bad ? -1 : k;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* NMS flooding decoder, edge-list form.                         */
+/*   tot[v] = (sum over the checks of v, ascending check index, of cv) + w_in * y[v]      */
+/*   vc = tot - cv;  sign(0) = 0;  a = min(|vc|, 1e30);  m1 <= m2 two smallest a;         */
+/*   mag = (a > m1) ? m1 : m2;  cv = (alpha * mag) * (S * s);  out = sum cv + w_out * y   */
+/* The ascending-check order is what a sequential dense reduce_sum(axis=1) gives          */
+/* (ms_test.py:132, :226); float results through TF itself are parity-unpinned.           */
+/* traj (optional): [T+1][B][n], slot 0 = y.  soft_out (optional): [B][n] final.          */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    int n, m, E;
+    int *chk_ptr;  /* m+1 */
+    int *chk_var;  /* E : variable of edge e (edges numbered check-major)   */
+    int *var_ptr;  /* n+1 */
+    int *var_edge; /* E : edge ids of variable v, ascending check           */
+} orc_graph;
+
+static orc_graph *graph_build(const int32_t *H, int m, int n)
+{
+    orc_graph *g = (orc_graph *)calloc(1, sizeof(*g));
+    g->n = n; g->m = m;
+    int E = 0;
+    for (size_t t = 0; t < (size_t)m * n; ++t) E += H[t] != 0;
+    g->E = E;
+    g->chk_ptr = (int *)malloc(sizeof(int) * (m + 1));
+    g->chk_var = (int *)malloc(sizeof(int) * E);
+    g->var_ptr = (int *)malloc(sizeof(int) * (n + 1));
+    g->var_edge = (int *)malloc(sizeof(int) * E);
+    int e = 0;
+    for (int c = 0; c < m; ++c) {
+        g->chk_ptr[c] = e;
+        for (int v = 0; v < n; ++v)
+            if (H[(size_t)c * n + v]) g->chk_var[e++] = v;
+    }
+    g->chk_ptr[m] = e;
+    int p = 0;
+    for (int v = 0; v < n; ++v) {
+        g->var_ptr[v] = p;
+        for (int c = 0; c < m; ++c)
+            if (H[(size_t)c * n + v])
+                for (int q = g->chk_ptr[c]; q < g->chk_ptr[c + 1]; ++q)
+                    if (g->chk_var[q] == v) g->var_edge[p++] = q;
+    }
+    g->var_ptr[n] = p;
+    return g;
+}
+
+static void graph_free(orc_graph *g)
+{
+    free(g->chk_ptr); free(g->chk_var); free(g->var_ptr); free(g->var_edge); free(g);
+}
+
+void orc_nms(const int32_t *H, int m, int n, const float *y, int64_t B, int T, const float *alpha,
+             float w_in, float w_out, float *traj, float *soft_out)
+{
+    orc_graph *g = graph_build(H, m, n);
+    float *cv = (float *)malloc(sizeof(float) * g->E);
+    float *tot = (float *)malloc(sizeof(float) * n);
+    for (int64_t b = 0; b < B; ++b) {
+        const float *yb = y + b * n;
+        float *last = NULL;
+        for (int e = 0; e < g->E; ++e) cv[e] = 0.0f;
+        if (traj) memcpy(traj + b * n, yb, sizeof(float) * n);
+        if (T == 0 && soft_out) memcpy(soft_out + b * n, yb, sizeof(float) * n);
+        for (int it = 0; it < T; ++it) {
+            for (int v = 0; v < n; ++v) {
+                float acc = 0.0f;
+                for (int q = g->var_ptr[v]; q < g->var_ptr[v + 1]; ++q) acc = acc + cv[g->var_edge[q]];
+                tot[v] = acc + yb[v] * w_in;
+            }
+            for (int c = 0; c < m; ++c) {
+                int e0 = g->chk_ptr[c], e1 = g->chk_ptr[c + 1];
+                float m1 = INFINITY, m2 = INFINITY;
+                int neg = 0, zero = 0;
+                for (int e = e0; e < e1; ++e) {
+                    float vc = tot[g->chk_var[e]] - cv[e];
+                    cv[e] = vc;
+                    float a = fminf(fabsf(vc), 1e30f);
+                    if (a < m1) { m2 = m1; m1 = a; } else if (a < m2) m2 = a;
+                    neg ^= (vc < 0.0f);
+                    zero |= (vc == 0.0f);
+                }
+                for (int e = e0; e < e1; ++e) {
+                    float vc = cv[e];
+                    float a = fminf(fabsf(vc), 1e30f);
+                    float mag = (a > m1) ? m1 : m2;
+                    float s = (vc > 0.0f) ? 1.0f : ((vc < 0.0f) ? -1.0f : 0.0f);
+                    float S = zero ? 0.0f : (neg ? -1.0f : 1.0f);
+                    cv[e] = (alpha[it] * mag) * (S * s);
+                }
+            }
+            last = traj ? traj + ((int64_t)(it + 1) * B + b) * n : (soft_out ? soft_out + b * n : tot);
+            for (int v = 0; v < n; ++v) {
+                float acc = 0.0f;
+                for (int q = g->var_ptr[v]; q < g->var_ptr[v + 1]; ++q) acc = acc + cv[g->var_edge[q]];
+                last[v] = acc + w_out * yb[v];
+            }
+        }
+        if (traj && soft_out && T > 0) memcpy(soft_out + b * n, last, sizeof(float) * n);
+    }
+    free(cv); free(tot); graph_free(g);
+}
+
+/* get_eval (ms_test.py:36-54).  hard: [B][n] uint8 out (optional), fail: [B] uint8 out       */
+/* counts: {frames, frame_err, bit_err, undetected, synd_fail}                                */
+void orc_eval(const int32_t *H, int m, int n, const float *soft, const uint8_t *labels, int64_t B,
+              uint8_t *hard, uint8_t *fail, int64_t *counts)
+{
+    uint8_t hb[ORC_MAX_N];
+    int64_t ferr = 0, berr = 0, und = 0, sf = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        int nerr = 0, bad = 0;
+        for (int v = 0; v < n; ++v) {
+            hb[v] = soft[b * n + v] > 0.0f ? 0 : 1;
+            if (labels) nerr += hb[v] != labels[b * n + v];
+        }
+        for (int c = 0; c < m; ++c) {
+            int acc = 0;
+            for (int v = 0; v < n; ++v) acc ^= (H[(size_t)c * n + v] & hb[v]);
+            bad |= acc;
+        }
+        if (hard) memcpy(hard + b * n, hb, (size_t)n);
+        if (fail) fail[b] = (uint8_t)bad;
+        ferr += nerr != 0; berr += nerr; sf += bad; und += (!bad && nerr != 0);
+    }
+    if (counts) { counts[0] = B; counts[1] = ferr; counts[2] = berr; counts[3] = und; counts[4] = sf; }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* OSD front end (pb_testing.py:268-320).                                                 */
+/*   pi1 = argsort(|y|) descending, ties -> lower index (tf.argsort leaves ties open)     */
+/*   GE on G[:, pi1]; swaps replayed on 0..n-1; MRB/LRB halves sorted ascending;          */
+/*   P'[r][c] = P[sm[r]][sl[c]];  perm[p] = pi1[pi2[p]].                                   */
+/* Outputs: perm [n], Gp [k][n] (=[I|P']), swaps [<=n][2], nswaps.                         */
+/* ------------------------------------------------------------------------------------ */
+static void stable_sort_desc_abs(const float *y, int n, int32_t *idx)
+{
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    for (int i = 1; i < n; ++i) { /* insertion sort: stable */
+        int32_t t = idx[i];
+        float a = fabsf(y[t]);
+        int j = i - 1;
+        while (j >= 0 && fabsf(y[idx[j]]) < a) { idx[j + 1] = idx[j]; --j; }
+        idx[j + 1] = t;
+    }
+}
+
+static void argsort_small(const int32_t *v, int n, int32_t *order)
+{
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i) {
+        int32_t t = order[i];
+        int j = i - 1;
+        while (j >= 0 && v[order[j]] > v[t]) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = t;
+    }
+}
+
+int orc_osd_front(const int32_t *G, int k, int n, const float *y, int32_t *perm, int32_t *Gp,
+                  int32_t *swaps, int32_t *nswaps)
+{
+    int32_t pi1[ORC_MAX_N], idx[ORC_MAX_N], sm[ORC_MAX_N], sl[ORC_MAX_N];
+    int32_t *M = (int32_t *)malloc(sizeof(int32_t) * (size_t)k * n);
+    int32_t lsw[2 * ORC_MAX_N], ns = 0;
+    stable_sort_desc_abs(y, n, pi1);
+    for (int r = 0; r < k; ++r)
+        for (int c = 0; c < n; ++c) M[(size_t)r * n + c] = G[(size_t)r * n + pi1[c]];
+    int rows = orc_gf2elim(M, k, n, lsw, &ns);
+    if (rows != k) { free(M); return -1; }
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    for (int s = 0; s < ns; ++s) {
+        int32_t t = idx[lsw[2 * s]];
+        idx[lsw[2 * s]] = idx[lsw[2 * s + 1]];
+        idx[lsw[2 * s + 1]] = t;
+    }
+    argsort_small(idx, k, sm);
+    argsort_small(idx + k, n - k, sl);
+    for (int r = 0; r < k; ++r) {
+        for (int c = 0; c < k; ++c) Gp[(size_t)r * n + c] = (r == c);
+        for (int c = 0; c < n - k; ++c) Gp[(size_t)r * n + k + c] = M[(size_t)sm[r] * n + k + sl[c]];
+    }
+    for (int p = 0; p < k; ++p) perm[p] = pi1[idx[sm[p]]];
+    for (int p = 0; p < n - k; ++p) perm[k + p] = pi1[idx[k + sl[p]]];
+    if (swaps) memcpy(swaps, lsw, sizeof(int32_t) * 2 * (size_t)ns);
+    if (nswaps) *nswaps = ns;
+    free(M);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* TEP table (convention_osd.py:13-38): weight 0..order, each weight class = lexicographic */
+/* combinations stably re-sorted by descending index sum.  supports: [Tn][3] uint8, 0xFF   */
+/* padded.  Returns Tn (pass supports == NULL to size).  order <= 3.                       */
+/* ------------------------------------------------------------------------------------ */
+static int64_t choose(int n, int r)
+{
+    int64_t v = 1;
+    for (int i = 1; i <= r; ++i) v = v * (n - r + i) / i;
+    return v;
+}
+
+int64_t orc_tep_table(int k, int order, uint8_t *supports)
+{
+    int64_t total = 0;
+    for (int w = 0; w <= order; ++w) total += choose(k, w);
+    if (!supports) return total;
+    int64_t base = 0;
+    for (int w = 0; w <= order; ++w) {
+        int64_t cnt = choose(k, w);
+        int maxsum = w * k;
+        int64_t *bucket = (int64_t *)calloc((size_t)maxsum + 2, sizeof(int64_t));
+        /* pass 1: histogram of index sums; pass 2: stable placement, descending sum */
+        for (int pass = 0; pass < 2; ++pass) {
+            int c[3] = {0, 1, 2};
+            if (pass == 1) { /* bucket[s] := start offset of sum s when ordered by descending s */
+                int64_t acc = 0;
+                for (int s = maxsum; s >= 0; --s) { int64_t t = bucket[s]; bucket[s] = acc; acc += t; }
+            }
+            for (int64_t t = 0; t < cnt; ++t) {
+                int s = 0;
+                for (int q = 0; q < w; ++q) s += c[q];
+                if (pass == 0) bucket[s]++;
+                else {
+                    uint8_t *dst = supports + 3 * (base + bucket[s]++);
+                    for (int q = 0; q < 3; ++q) dst[q] = q < w ? (uint8_t)c[q] : 0xFF;
+                }
+                /* next lexicographic combination */
+                int q = w - 1;
+                while (q >= 0 && c[q] == k - w + q) --q;
+                if (q < 0) break;
+                ++c[q];
+                for (int z = q + 1; z < w; ++z) c[z] = c[z - 1] + 1;
+            }
+        }
+        free(bucket);
+        base += cnt;
+    }
+    return total;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Shared OSD candidate machinery for k = n - k = 64 (one u64 parity word per G' row).    */
+/* Canonical cost order (see oracle/np_oracle.py weighted_distance): flipped-MRB weights   */
+/* ascending and sequential, then parity bytes 0..7 each summed ascending from 0, added    */
+/* in byte order.  The per-byte sums are tabulated (lut[b][v]) -- same values by           */
+/* construction.                                                                          */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    float w[128];       /* |y'| */
+    uint64_t P[64];     /* parity part of G' rows */
+    uint64_t d0;        /* parity discrepancy of the order-0 candidate */
+    uint64_t hm, hp;    /* hard decisions: MRB word, parity word */
+    float lut[8][256];
+} osd_frame;
+
+static void frame_prepare(osd_frame *f, const float *yp, const int32_t *Gp)
+{
+    f->hm = f->hp = 0;
+    for (int p = 0; p < 128; ++p) {
+        f->w[p] = fabsf(yp[p]);
+        uint64_t bit = yp[p] > 0.0f ? 0 : 1;
+        if (p < 64) f->hm |= bit << p; else f->hp |= bit << (p - 64);
+    }
+    for (int r = 0; r < 64; ++r) {
+        uint64_t wv = 0;
+        for (int c = 0; c < 64; ++c) wv |= (uint64_t)(Gp[r * 128 + 64 + c] & 1) << c;
+        f->P[r] = wv;
+    }
+    uint64_t c0 = 0;
+    for (int r = 0; r < 64; ++r) if ((f->hm >> r) & 1) c0 ^= f->P[r];
+    f->d0 = c0 ^ f->hp;
+    for (int b = 0; b < 8; ++b) {
+        f->lut[b][0] = 0.0f;
+        for (int t = 0; t < 8; ++t)
+            for (int v = 1 << t; v < (2 << t); ++v) f->lut[b][v] = f->lut[b][v - (1 << t)] + f->w[64 + 8 * b + t];
+    }
+}
+
+static inline float frame_cost(const osd_frame *f, float mrb, uint64_t D)
+{
+    float acc = mrb;
+    for (int b = 0; b < 8; ++b) acc = acc + f->lut[b][(D >> (8 * b)) & 0xFF];
+    return acc;
+}
+
+static void codeword_to_original(const osd_frame *f, uint64_t mrb_bits, uint64_t D, const int32_t *perm,
+                                 uint8_t *cw_orig)
+{
+    uint64_t par = D ^ f->hp; /* candidate parity bits */
+    for (int p = 0; p < 64; ++p) cw_orig[perm[p]] = (uint8_t)((mrb_bits >> p) & 1);
+    for (int p = 0; p < 64; ++p) cw_orig[perm[64 + p]] = (uint8_t)((par >> p) & 1);
+}
+
+/* convention_osd_main (convention_osd.py:49-76) for one frame of the (128,64) code.     */
+/* Inputs are ORIGINAL-order y (and optional label); the front end is run inside.        */
+/* out_i32: {best_tep_index, phase(-1 if wrong or no label), correct, teps_size, nswaps}  */
+int orc_conv_osd(const int32_t *G, const float *y, const uint8_t *label, int order, const uint8_t *teps,
+                 int64_t ntep, int32_t *out_i32, float *out_metric, uint8_t *cw_orig)
+{
+    int32_t perm[128], Gp[64 * 128], ns = 0;
+    float yp[128];
+    osd_frame f;
+    if (orc_osd_front(G, 64, 128, y, perm, Gp, NULL, &ns)) return -1;
+    for (int p = 0; p < 128; ++p) yp[p] = y[perm[p]];
+    frame_prepare(&f, yp, Gp);
+    float best = 0.0f; int64_t besti = -1; uint64_t bestD = 0, bestE = 0;
+    for (int64_t t = 0; t < ntep; ++t) {
+        const uint8_t *s = teps + 3 * t;
+        uint64_t D = f.d0, E = 0; float mrb = 0.0f;
+        for (int q = 0; q < 3 && s[q] != 0xFF; ++q) { D ^= f.P[s[q]]; E |= 1ull << s[q]; mrb = mrb + f.w[s[q]]; }
+        float c = frame_cost(&f, mrb, D);
+        if (besti < 0 || c < best) { best = c; besti = t; bestD = D; bestE = E; }
+    }
+    uint8_t cw[128];
+    codeword_to_original(&f, f.hm ^ bestE, bestD, perm, cw);
+    int correct = 0, phase = -1;
+    if (label) {
+        correct = memcmp(cw, label, 128) == 0;
+        if (correct) {
+            int64_t acc = 0;
+            for (int w = 0; w <= order; ++w) { acc += choose(64, w); if (besti < acc) { phase = w; break; } }
+        }
+    }
+    out_i32[0] = (int32_t)besti; out_i32[1] = phase; out_i32[2] = correct; out_i32[3] = (int32_t)ntep; out_i32[4] = ns;
+    if (out_metric) *out_metric = best;
+    if (cw_orig) memcpy(cw_orig, cw, 128);
+    return 0;
+}
+
+/* batch wrapper used by the cpu_baseline leg and the parity tests */
+int orc_conv_osd_batch(const int32_t *G, const float *y, const uint8_t *labels, int64_t F, int order,
+                       int32_t *out_i32 /*[F][5]*/, float *out_metric /*[F]*/, uint8_t *cw_orig /*[F][128]*/)
+{
+    int64_t ntep = orc_tep_table(64, order, NULL);
+    uint8_t *teps = (uint8_t *)malloc((size_t)ntep * 3);
+    orc_tep_table(64, order, teps);
+    int rc = 0;
+    for (int64_t i = 0; i < F && !rc; ++i)
+        rc = orc_conv_osd(G, y + i * 128, labels ? labels + i * 128 : NULL, order, teps, ntep, out_i32 + 5 * i,
+                          out_metric ? out_metric + i : NULL, cw_orig ? cw_orig + i * 128 : NULL);
+    free(teps);
+    return rc;
+}

@@ -1,0 +1,417 @@
+"""NumPy oracle -- TEST INFRASTRUCTURE ONLY.
+
+A CPU restatement of the reference's NMS + OSD hot path, written as close to the
+reference's *dense / per-frame* formulation as NumPy allows, so that it can be read
+side by side with the reference.  Nothing in the product package
+(``short_ldpc_decoding_osd_amd/``) may import this module; only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * alist loader, G construction and the GF(2) elimination rule are pinned against the
+    reference's own importable NumPy module ``fill_matrix_info.py`` through the golden
+    fixtures in ``tests/golden`` (made by ``oracle/gen_golden.py``).
+  * everything that the reference executes through TensorFlow (NMS float math, argsort,
+    reduce_sum order) is a restatement of the cited lines; TensorFlow is absent from the
+    build image, the reference ships no test vectors, so those float results are
+    **parity unpinned** (GF(2)/integer parts remain pinned through the shared GE rule).
+
+All file:line citations are relative to /root/reference/LDPC_128/.
+"""
+from __future__ import annotations
+
+import itertools
+import math
+
+import numpy as np
+
+F32 = np.float32
+
+# --------------------------------------------------------------------------------------
+# code definition:  Ldpc_128_testing/fill_matrix_info.py
+# --------------------------------------------------------------------------------------
+
+
+def load_alist(path):
+    """alist text -> dense H[m,n] int64.  (fill_matrix_info.py:70-104)
+
+    Line 1 ``n m``; line 2 max degrees; lines 3-4 degree lists (ignored by the
+    reference too); then n lines of 1-based check ids per variable; tokens ``'0'`` and
+    ``''`` are padding (:96).  The m check lines that follow are parsed by the reference
+    but never used for H, so they are not read here.
+    """
+    with open(path, "rt") as fh:
+        rows = [ln.rstrip("\n").split(" ") for ln in fh]
+    n, m = (int(t) for t in rows[0][:2])
+    max_var_deg, max_chk_deg = (int(t) for t in rows[1][:2])
+    H = np.zeros((m, n), dtype=np.int64)
+    for v in range(n):
+        for tok in rows[4 + v]:
+            if tok not in ("0", ""):
+                H[int(tok) - 1, v] = 1
+    return H, max_chk_deg
+
+
+def gf2_eliminate(M):
+    """Gauss-Jordan over GF(2) with the reference's pivoting rule.
+
+    Restates ``full_gf2elim`` (PB_OSD/pb_testing.py:231-266), which is textually the same
+    routine as ``Code.gf2elim`` (fill_matrix_info.py:7-42).  Works on a copy; returns the
+    reduced matrix and the list of recorded column exchanges ``(j, col)``.
+
+      for i = j = 0.. :  pivot = first row >= i with a 1 in column j          (:238-245)
+                         none -> if row i is all-zero from j on: drop the row (:247-250)
+                                 else swap column j with the first column >= j
+                                 holding a 1 *in row i*, and record it        (:251-256)
+                         clear column j in every other row (XOR of columns j:) (:258-262)
+    """
+    M = np.array(M, dtype=np.int64, copy=True)
+    swaps = []
+    i = j = 0
+    m, n = M.shape
+    while i < m and j < n:
+        below = np.flatnonzero(M[i:, j])
+        if below.size:
+            r = i + int(below[0])
+            if r != i:
+                M[[i, r]] = M[[r, i]]
+        else:
+            right = np.flatnonzero(M[i, j:])
+            if right.size == 0:
+                M = np.delete(M, i, axis=0)
+                m -= 1
+                continue
+            c = j + int(right[0])
+            M[:, [j, c]] = M[:, [c, j]]
+            swaps.append((j, c))
+        hit = M[:, j].astype(bool)
+        hit[i] = False
+        M[hit, j:] ^= M[i, j:]
+        i += 1
+        j += 1
+    return M, swaps
+
+
+def generator_from_H(H):
+    """Systematic-form generator from H.  (fill_matrix_info.py:44-69)
+
+    GE gives ``[I | H2]``; ``G = [H2^T | I]``; the recorded column exchanges are undone in
+    reverse order; ``H G^T = 0`` is asserted (the reference only prints, :63-68).
+    """
+    R, swaps = gf2_eliminate(H)
+    m = R.shape[0]
+    n = R.shape[1]
+    G = np.concatenate([R[:, m:].T, np.eye(n - m, dtype=np.int64)], axis=1)
+    for a, b in reversed(swaps):
+        G[:, [a, b]] = G[:, [b, a]]
+    assert not (H.dot(G.T) % 2).any(), "H G^T != 0"
+    return G
+
+
+class Code:
+    """Attribute-compatible with the reference's ``Code`` (fill_matrix_info.py:3-129)."""
+
+    def __init__(self, path):
+        self.H, self.max_chk_degree = load_alist(path)
+        self.check_matrix_row, self.check_matrix_column = self.H.shape
+        self.G = generator_from_H(self.H)
+        self.k = self.G.shape[0]
+
+
+# --------------------------------------------------------------------------------------
+# synthetic test frames:  Testing_data_gen_128/data_generating.py:13-51
+# --------------------------------------------------------------------------------------
+
+
+def snr_to_sigma(snr_db, k, n):
+    """sigma = sqrt(1 / (2 R 10^(snr/10)))   (data_generating.py:17)"""
+    return math.sqrt(1.0 / (2.0 * (float(k) / float(n)) * 10.0 ** (snr_db / 10.0)))
+
+
+def make_frames(G, snr_db, frames, rng):
+    """AWGN test frames: BPSK 0->+1, unit mean, no LLR scaling (:40-51).
+
+    The reference draws from the unseeded global NumPy RNG (:10); here a Generator is
+    passed in.  Returns (y float32 [F,n], codewords int64 [F,n]).
+    """
+    k, n = G.shape
+    sigma = snr_to_sigma(snr_db, k, n)
+    chan = rng.normal(1.0, sigma, size=(frames, n))
+    msg = rng.integers(0, 2, size=(frames, k))
+    cw = msg.dot(G) % 2
+    y = np.where(cw == 0, chan, -chan)
+    return y.astype(F32), cw.astype(np.int64)
+
+
+# --------------------------------------------------------------------------------------
+# NMS belief propagation, dense mirror:  Ldpc_128_testing/ms_test.py:99-242
+# --------------------------------------------------------------------------------------
+
+
+def softplus(x):
+    return F32(np.log1p(np.exp(np.float64(x))))
+
+
+def nms_dense(y, H, T, alpha, w_in=1.0, w_out=1.0):
+    """Op-for-op dense mirror of ``Decoder_Layer`` for NMS-1/2/3 (float32 throughout).
+
+    y [B,n] f32; alpha = effective check normaliser (softplus of the stored weight,
+    ms_test.py:207-208), scalar or length-T; w_in / w_out = effective bit weights of
+    NMS-2/3 (:127-131, :222-225; 1.0 for NMS-1).  Returns the list
+    ``[y, out_1, ..., out_T]`` (:106-109, :228).
+    """
+    y = np.asarray(y, dtype=F32)
+    B, n = y.shape
+    m = H.shape[0]
+    Hf = H.astype(F32)
+    alpha = np.broadcast_to(np.asarray(alpha, dtype=F32), (T,))
+    w_in = F32(w_in)
+    w_out = F32(w_out)
+    cv = np.zeros((B, m, n), dtype=F32)                                # :117
+    outs = [y]
+    back = np.where(H == 0, F32(-1e30) - F32(1), F32(0)).astype(F32)   # :193
+    for it in range(T):
+        # compute_vc :124-137
+        tot = cv.sum(axis=1, dtype=F32) + y * w_in
+        vc = tot[:, None, :] * Hf - cv
+        # compute_cv2 signs :183-191
+        sgn = np.sign((F32(1) - Hf)[None] + vc).astype(F32)
+        rowprod = np.prod(sgn, axis=2, keepdims=True, dtype=F32)
+        out_sign = (rowprod * Hf) * sgn
+        # magnitudes :193-206
+        a = np.clip(np.abs(vc), F32(0), F32(1e30))
+        decision = -np.abs(a) + back[None]
+        part = -np.sort(-decision, axis=2)[:, :, :2]                    # top_k(k=2) values
+        m1 = (-part[:, :, 0:1]) * Hf
+        m2 = (-part[:, :, 1:2]) * Hf
+        mag = np.where(a > m1, m1, m2)
+        cv = (alpha[it] * mag * out_sign).astype(F32)                   # :207-209
+        # marginalize :220-228
+        outs.append((cv.sum(axis=1, dtype=F32) + w_out * y).astype(F32))
+    return outs
+
+
+def nms_sparse(y, H, T, alpha, w_in=1.0, w_out=1.0):
+    """Edge-list restatement of the same math (Appendix A.1 of SURVEY.md).
+
+    Per-variable sums run over the variable's checks in ascending check index and add the
+    channel value last -- the order a sequential dense ``reduce_sum(axis=1)`` (ms_test.py:132)
+    produces, since adding the zero entries of non-edges is exact.  This is the order the
+    C oracle and the HIP kernels follow bit-for-bit.
+    """
+    y = np.asarray(y, dtype=F32)
+    B, n = y.shape
+    m = H.shape[0]
+    alpha = np.broadcast_to(np.asarray(alpha, dtype=F32), (T,))
+    w_in = F32(w_in)
+    w_out = F32(w_out)
+    chk_vars = [np.flatnonzero(H[c]) for c in range(m)]
+    var_chks = [np.flatnonzero(H[:, v]) for v in range(n)]
+    cv = {(c, v): np.zeros(B, dtype=F32) for c in range(m) for v in chk_vars[c]}
+    outs = [y]
+    for it in range(T):
+        tot = np.zeros((B, n), dtype=F32)
+        for v in range(n):
+            acc = np.zeros(B, dtype=F32)
+            for c in var_chks[v]:
+                acc = acc + cv[(c, v)]
+            tot[:, v] = acc + y[:, v] * w_in
+        new = {}
+        for c in range(m):
+            vs = chk_vars[c]
+            vc = np.stack([tot[:, v] - cv[(c, v)] for v in vs], axis=1)      # [B,deg]
+            s = np.sign(vc).astype(F32)
+            S = np.prod(s, axis=1, dtype=F32)
+            a = np.minimum(np.abs(vc), F32(1e30))
+            srt = np.sort(a, axis=1)
+            m1, m2 = srt[:, 0], srt[:, 1]
+            for e, v in enumerate(vs):
+                mag = np.where(a[:, e] > m1, m1, m2)
+                new[(c, v)] = (alpha[it] * mag * (S * s[:, e])).astype(F32)
+        cv = new
+        out = np.zeros((B, n), dtype=F32)
+        for v in range(n):
+            acc = np.zeros(B, dtype=F32)
+            for c in var_chks[v]:
+                acc = acc + cv[(c, v)]
+            out[:, v] = acc + w_out * y[:, v]
+        outs.append(out)
+    return outs
+
+
+def hard_decision(soft):
+    """bit = 0 iff soft > 0; a value of exactly 0 decodes to 1.  (ms_test.py:39)"""
+    return np.where(np.asarray(soft) > 0, 0, 1).astype(np.int64)
+
+
+def evaluate(soft_final, labels, H):
+    """``Decoding_model.get_eval`` (ms_test.py:36-54).
+
+    Returns (FER, BER, undetected_count, failed_index) where failed_index are the frames
+    with a non-zero syndrome, ascending (what ``tf.where(syndrome!=0)`` yields, :51).
+    """
+    hard = hard_decision(soft_final)
+    err_bits = (hard != labels).sum(axis=1)
+    syndrome = (hard.dot(H.T) % 2).sum(axis=1)
+    ok = err_bits == 0
+    undetected = int(np.count_nonzero((syndrome == 0) & ~ok))
+    B, n = labels.shape
+    fer = 1.0 - np.count_nonzero(ok) / B
+    ber = err_bits.sum() / (B * n)
+    return fer, ber, undetected, np.flatnonzero(syndrome != 0)
+
+
+def collect_failed(outs, labels, failed_index):
+    """``collect_failed_output_selective`` (ms_test.py:55-64): T+1 rows per failed frame,
+    row 0 = channel values, row j = soft output after iteration j; label repeated."""
+    rows, labs = [], []
+    for i in failed_index:
+        for o in outs:
+            rows.append(o[i])
+            labs.append(labels[i])
+    return rows, labs
+
+
+# --------------------------------------------------------------------------------------
+# OSD front end:  PB_OSD/pb_testing.py:268-320  (== FS_OSD/fs_testing.py:270-322)
+# --------------------------------------------------------------------------------------
+
+
+def reliability_order(y):
+    """pi_1 = argsort(|y|) descending (pb_testing.py:309-310).  ``tf.argsort`` is not
+    stable, so the reference leaves ties unspecified; the build defines them as
+    "lower original index first" (stable)."""
+    return np.argsort(-np.abs(np.asarray(y, dtype=F32)), kind="stable")
+
+
+def identify_mrb(G_ordered, k):
+    """``identify_mrb`` (pb_testing.py:268-304) on an already column-permuted G.
+
+    Returns (G' = [I | P'] int64, pi_2 int64[n], swaps).
+    """
+    n = G_ordered.shape[1]
+    R, swaps = gf2_eliminate(G_ordered)                       # :272-274
+    idx = np.arange(n)
+    for a, b in swaps:                                        # :276-281
+        idx[a], idx[b] = idx[b], idx[a]
+    mrb, lrb = idx[:k], idx[k:]                               # :283, :291
+    sm = np.argsort(mrb, kind="stable")                       # :284  (entries are distinct)
+    sl = np.argsort(lrb, kind="stable")                       # :292
+    P = R[:, k:][:, sl]                                       # :294
+    Pp = P[sm, :]                                             # :287-298: Pi^T . P  <=> row r <- row sm[r]
+    Gp = np.concatenate([np.eye(k, dtype=np.int64), Pp], axis=1)   # :300
+    pi2 = np.concatenate([mrb[sm], lrb[sl]])                  # :302
+    return Gp, pi2, swaps
+
+
+def swapped_info(y, label, G):
+    """``swapped_info`` (pb_testing.py:306-320).  Returns (y', label', G', perm, swaps) with
+    ``perm[p]`` = original bit index that sits at primed position p (= pi_1[pi_2[p]])."""
+    y = np.asarray(y, dtype=F32)
+    k = G.shape[0]
+    pi1 = reliability_order(y)
+    Gp, pi2, swaps = identify_mrb(G[:, pi1], k)
+    perm = pi1[pi2]
+    return y[perm], np.asarray(label)[perm], Gp, perm, swaps
+
+
+# --------------------------------------------------------------------------------------
+# test error patterns + conventional order-p OSD:  FS_OSD/convention_osd.py:13-76
+# --------------------------------------------------------------------------------------
+
+
+def tep_table(k, order):
+    """``generate_teps`` (convention_osd.py:13-38): for w = 0..order, every weight-w support
+    in lexicographic ``itertools.combinations`` order, *stably* re-sorted by descending sum
+    of the support indices (:19-24), concatenated.  Returns a list of index tuples."""
+    table = []
+    for w in range(order + 1):
+        combos = list(itertools.combinations(range(k), w))
+        combos.sort(key=lambda s: -sum(s))
+        table.extend(combos)
+    return table
+
+
+def tep_boundaries(k, order):
+    """``query_boundary`` (convention_osd.py:39-47): cumulative C(k,w)."""
+    out, acc = [], 0
+    for w in range(order + 1):
+        acc += math.comb(k, w)
+        out.append(acc)
+    return out
+
+
+def tep_matrix(k, order):
+    t = tep_table(k, order)
+    E = np.zeros((len(t), k), dtype=np.int64)
+    for r, s in enumerate(t):
+        E[r, list(s)] = 1
+    return E
+
+
+def weighted_distance(disc_bits, w):
+    """Canonical float32 evaluation order of  sum_p disc[p] * |y'[p]|.
+
+    The reference evaluates this with ``tf.reduce_sum`` over 128 terms
+    (convention_osd.py:60-61, pb_testing.py:106/137, fs_testing.py:62) whose internal order
+    is not specified.  The build fixes it as:   M   = flipped MRB weights, ascending
+    position, sequential;   L_b = parity byte b (positions k+8b .. k+8b+7), ascending,
+    sequential from 0;   cost = (((M + L_0) + L_1) + ...) + L_last.   The HIP kernels and
+    the C oracle follow exactly this order, so metrics are bit-identical; ``exact_distance``
+    gives the order-free float64 value used to show the choice is immaterial.
+    """
+    disc_bits = np.asarray(disc_bits)
+    w = np.asarray(w, dtype=F32)
+    n = w.shape[0]
+    k = n // 2 if n % 2 == 0 else None
+    return _weighted_distance_k(disc_bits, w, k)
+
+
+def _weighted_distance_k(disc_bits, w, k):
+    n = w.shape[0]
+    acc = F32(0)
+    for p in range(k):
+        if disc_bits[p]:
+            acc = F32(acc + w[p])
+    p = k
+    while p < n:
+        part = F32(0)
+        for q in range(p, min(p + 8, n)):
+            if disc_bits[q]:
+                part = F32(part + w[q])
+        acc = F32(acc + part)
+        p += 8
+    return acc
+
+
+def exact_distance(disc_bits, w):
+    return float(np.dot(np.asarray(disc_bits, dtype=np.float64), np.asarray(w, dtype=np.float64)))
+
+
+def convention_osd(yp, labelp, Gp, order, teps=None):
+    """``convention_osd_main`` (convention_osd.py:49-76), returning more than the
+    reference does: dict(correct, teps_size, phase, best_index, metric, codeword).
+
+    hard' = (y'>0 ? 0 : 1) (:54); candidates = ((TEP + hard'[:k]) % 2) . G' % 2 (:58-59);
+    cost = canonical weighted distance (:60-61); first minimum (:63); ``phase`` is the
+    order class of the winner if it equals the label, else -1 (:66-74).
+    """
+    yp = np.asarray(yp, dtype=F32)
+    k, n = Gp.shape
+    if teps is None:
+        teps = tep_matrix(k, order)
+    hard = np.where(yp > 0, 0, 1).astype(np.int64)
+    cand = ((teps + hard[None, :k]) % 2).dot(Gp) % 2
+    disc = (cand + hard[None, :]) % 2
+    w = np.abs(yp)
+    cost = np.array([_weighted_distance_k(d, w, k) for d in disc], dtype=F32)
+    best = int(np.argmin(cost))
+    correct = bool(np.array_equal(cand[best], np.asarray(labelp)))
+    phase = -1
+    if correct:
+        for i, b in enumerate(tep_boundaries(k, order)):
+            if best < b:
+                phase = i
+                break
+    return dict(correct=correct, teps_size=int(teps.shape[0]), phase=phase, best_index=best,
+                metric=cost[best], codeword=cand[best], costs=cost,
+                exact_best=int(np.argmin(disc.astype(np.float64).dot(w.astype(np.float64)))))

@@ -1,0 +1,127 @@
+"""The oracle against the reference's own outputs (tests/golden, made by oracle/gen_golden.py
+from the importable ``fill_matrix_info.py``) and the two oracle forms against each other."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, np_oracle
+
+CODES = {
+    "ccsds_128_64": "short_ldpc_decoding_osd_amd/data/CCSDS_ldpc_n128_k64.alist",
+    "array_121_60": "tests/golden/ArrayCode_N121_K60_r0.50.alist",
+    "ldpc_96_48": "tests/golden/LDPC_N96_K48_P8_set0_dmin10.alist",
+}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", sorted(CODES))
+def test_code_matches_reference(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"code_{name}.npz"))
+    H, mcd = np_oracle.load_alist(os.path.join(ROOT, CODES[name]))
+    assert np.array_equal(H, g["H"])
+    assert mcd == int(g["max_chk_degree"])
+    G = np_oracle.generator_from_H(H)
+    assert np.array_equal(G, g["G"]) and G.shape[0] == int(g["k"])
+    Gc = c_oracle.generator(H)
+    assert np.array_equal(Gc, g["G"])
+
+
+def test_gf2elim_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "gf2elim_ccsds.npz"))
+    G = np.load(os.path.join(golden_dir, "code_ccsds_128_64.npz"))["G"].astype(np.int64)
+    red = np.unpackbits(g["reduced"], axis=2)[:, :, :128]
+    for i in range(g["y"].shape[0]):
+        perm = g["perm"][i].astype(np.int64)
+        want_sw = [tuple(int(x) for x in r) for r in g["swaps"][i][: g["nswaps"][i]]]
+        M, sw = np_oracle.gf2_eliminate(G[:, perm])
+        assert np.array_equal(M, red[i]) and sw == want_sw, i
+        if i % 4 == 0 or g["nswaps"][i] > 4:
+            Mc, swc = c_oracle.gf2elim(G[:, perm])
+            assert np.array_equal(Mc, red[i]) and swc == want_sw, i
+
+
+def test_sort_rule_matches_golden_perm(golden_dir):
+    g = np.load(os.path.join(golden_dir, "gf2elim_ccsds.npz"))
+    for i in range(0, g["y"].shape[0], 7):
+        assert np.array_equal(np_oracle.reliability_order(g["y"][i]), g["perm"][i])
+
+
+def test_front_end_c_vs_numpy(np_code, golden_dir):
+    g = np.load(os.path.join(golden_dir, "gf2elim_ccsds.npz"))
+    for i in list(range(0, 384, 5)) + [381, 382, 383]:
+        y = g["y"][i]
+        yp, lp, Gp, perm, sw = np_oracle.swapped_info(y, np.zeros(128, dtype=np.int64), np_code.G)
+        permc, Gpc, swc = c_oracle.osd_front(np_code.G, y)
+        assert np.array_equal(perm, permc) and np.array_equal(Gp, Gpc) and sw == swc
+        assert np.array_equal(Gp[:, :64], np.eye(64, dtype=np.int64))
+        # G' spans the same code, seen through perm
+        assert not (np_code.H[:, perm].dot(Gp.T) % 2).any()
+
+
+@pytest.mark.parametrize("snr", [1.0, 2.5, 3.5])
+@pytest.mark.parametrize("T,alpha", [(1, 1.0), (10, 0.669435), (12, 0.8)])
+def test_nms_sparse_c_equals_dense_numpy(np_code, snr, T, alpha):
+    rng = np.random.default_rng(int(snr * 10) + T)
+    y, cw = np_oracle.make_frames(np_code.G, snr, 48, rng)
+    dense = np_oracle.nms_dense(y, np_code.H, T, alpha)
+    soft, traj = c_oracle.nms(np_code.H, y, T, alpha, want_traj=True)
+    for it in range(T + 1):
+        assert np.array_equal(dense[it], traj[it]), it
+    assert np.array_equal(soft, dense[-1])
+    fer, ber, und, idx = np_oracle.evaluate(dense[-1], cw, np_code.H)
+    hard, fail, cnt = c_oracle.evaluate(np_code.H, soft, cw)
+    assert np.array_equal(np.flatnonzero(fail), idx)
+    assert cnt["frame_err"] == round(fer * 48) and cnt["undetected"] == und
+    assert cnt["bit_err"] == round(ber * 48 * 128)
+
+
+def test_nms_variants_and_zero_llr(np_code):
+    rng = np.random.default_rng(5)
+    y, _ = np_oracle.make_frames(np_code.G, 2.0, 16, rng)
+    y[0, :5] = 0.0          # sign(0) = 0 kills whole check rows (ms_test.py:187)
+    y[1, 3] = -0.0
+    y[2] = 0.0
+    for w_in, w_out in [(1.0, 1.0), (0.9, 0.9), (0.8, 1.1)]:
+        dense = np_oracle.nms_dense(y, np_code.H, 6, [0.7, 0.7, 0.8, 0.8, 0.9, 1.0], w_in, w_out)
+        sparse = np_oracle.nms_sparse(y, np_code.H, 6, [0.7, 0.7, 0.8, 0.8, 0.9, 1.0], w_in, w_out)
+        soft, traj = c_oracle.nms(np_code.H, y, 6, [0.7, 0.7, 0.8, 0.8, 0.9, 1.0], w_in, w_out, want_traj=True)
+        for it in range(7):
+            assert np.array_equal(dense[it], traj[it])
+            assert np.array_equal(dense[it], sparse[it])
+
+
+def test_tep_table(np_code):
+    for order in range(4):
+        t = c_oracle.tep_table(64, order)
+        assert t.shape[0] == np_oracle.tep_boundaries(64, order)[-1]
+        if order <= 2:
+            ref = np_oracle.tep_table(64, order)
+            got = [tuple(int(x) for x in r if x != 255) for r in t]
+            assert got == ref
+    t2 = c_oracle.tep_table(64, 2)
+    # SURVEY Appendix A.3 spot values
+    assert [tuple(r[:1]) for r in t2[1:4]] == [(63,), (62,), (61,)]
+    assert [tuple(r[:2]) for r in t2[65:71]] == [(62, 63), (61, 63), (60, 63), (61, 62), (59, 63), (60, 62)]
+    assert np_oracle.tep_boundaries(64, 3) == [1, 65, 2081, 43745]
+
+
+def test_conv_osd_c_vs_numpy(np_code):
+    rng = np.random.default_rng(77)
+    y, cw = np_oracle.make_frames(np_code.G, 2.5, 400, rng)
+    soft = c_oracle.nms(np_code.H, y, 10, 0.669435)
+    _, fail, _ = c_oracle.evaluate(np_code.H, soft, cw)
+    idx = np.flatnonzero(fail)[:24]
+    for order in (0, 1, 2):
+        res = c_oracle.conv_osd(np_code.G, y[idx], cw[idx], order)
+        for j, i in enumerate(idx):
+            yp, lp, Gp, perm, sw = np_oracle.swapped_info(y[i], cw[i], np_code.G)
+            r = np_oracle.convention_osd(yp, lp, Gp, order)
+            assert r["best_index"] == res["best"][j]
+            assert r["metric"] == res["metric"][j]
+            assert r["correct"] == res["correct"][j] and r["phase"] == res["phase"][j]
+            cw_o = np.empty(128, dtype=np.int64)
+            cw_o[perm] = r["codeword"]
+            assert np.array_equal(cw_o, res["codeword"][j])
+            assert not (np_code.H.dot(cw_o) % 2).any()
+            assert r["exact_best"] == r["best_index"]          # summation order is immaterial here
