@@ -1,0 +1,187 @@
+/*
+ * ldpc_osd.h -- C ABI of libldpcosd.so: MI355X (gfx950) short-LDPC NMS + OSD decoder.
+ *
+ * This is the drop-in boundary for the reference's decoding hot path.  The reference
+ * (lgw-frank/Short_LDPC_Decoding_OSD) has no FFI of its own -- its boundary is a Python
+ * call surface -- so every entry point cites the reference function it replaces
+ * (file:line relative to LDPC_128/ in the reference tree).  The Python mirror of that
+ * surface lives in short_ldpc_decoding_osd_amd/ and binds these symbols with ctypes;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; `stream` is a hipStream_t passed as void* (NULL = default stream)
+ *   - pointers named d_* are DEVICE pointers owned by the caller (e.g. torch tensors'
+ *     data_ptr()); all other pointers are host memory
+ *   - every call returns 0 on success or a negative LDPC_E_* code; ldpc_last_error()
+ *     returns a thread-local message.  Nothing aborts or throws across the ABI.
+ *   - device calls are asynchronous on `stream`; no allocation and no host sync happens
+ *     inside a decode call (graph-capturable)
+ *   - bit packing: bit v of a frame lives in word v/64, bit position v%64 (LSB first)
+ */
+#ifndef LDPC_OSD_H
+#define LDPC_OSD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDPC_OSD_ABI_VERSION 1
+
+enum {
+    LDPC_OK = 0,
+    LDPC_E_ARG = -1,         /* bad argument (null pointer, size, order ...)          */
+    LDPC_E_IO = -2,          /* cannot read / parse a file                            */
+    LDPC_E_CODE = -3,        /* H.G^T != 0, rank problems                             */
+    LDPC_E_HIP = -4,         /* a HIP runtime call failed (message has the details)   */
+    LDPC_E_UNSUPPORTED = -5, /* shape not handled by the kernels (e.g. OSD on n != 128) */
+    LDPC_E_NOMEM = -6
+};
+
+/* OSD search algorithms for ldpc_osd_decode */
+enum {
+    LDPC_OSD_CONVENTIONAL = 0, /* FS_OSD/convention_osd.py:49-76  convention_osd_main */
+    LDPC_OSD_FS = 1,           /* FS_OSD/fs_testing.py:129-161    fs_osd               */
+    LDPC_OSD_PB = 2            /* PB_OSD/pb_testing.py:100-149    pb_osd               */
+};
+
+/* NMS kernel selection (0 = let the library choose) */
+enum {
+    LDPC_NMS_AUTO = 0,
+    LDPC_NMS_GENERIC = 1, /* any code: one frame per wavefront, messages staged in LDS  */
+    LDPC_NMS_QC16 = 2     /* 16x16-circulant codes of the CCSDS (128,64) shape: one frame
+                             per 16-lane DPP row, messages in registers                  */
+};
+
+typedef struct ldpc_code ldpc_code; /* host-side code definition (H, G, Tanner graph) */
+typedef struct ldpc_ctx ldpc_ctx;   /* per-device constants + scratch                  */
+
+const char *ldpc_last_error(void);
+int ldpc_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Code definition (host, one-time).
+ * Replaces Ldpc_128_testing/fill_matrix_info.py: Code.load_code :70-129 (alist -> H),
+ * Code.gf2elim :7-42 and Code.generator_matrix :44-69 (systematic G, H.G^T = 0 check).
+ * ------------------------------------------------------------------------------------- */
+int ldpc_code_from_alist(const char *path, ldpc_code **out);
+int ldpc_code_from_dense(const int32_t *H /*[m][n] row-major 0/1*/, int32_t m, int32_t n, ldpc_code **out);
+void ldpc_code_destroy(ldpc_code *code);
+int ldpc_code_dims(const ldpc_code *code, int32_t *n, int32_t *m, int32_t *k, int32_t *max_chk_degree);
+int ldpc_code_get_H(const ldpc_code *code, int32_t *H /*[m][n]*/);
+int ldpc_code_get_G(const ldpc_code *code, int32_t *G /*[k][n]*/);
+
+/* GF(2) Gauss-Jordan with the reference's pivot rule on one host matrix, in place.
+ * Replaces full_gf2elim, PB_OSD/pb_testing.py:231-266 (used for code construction; the
+ * per-frame eliminations of the OSD run on the device, see ldpc_osd_ge).
+ * swaps: [n][2] pairs (j, col); *rows_out = rows left after deleting all-zero rows.     */
+int ldpc_gf2elim_host(int32_t *M /*[m][n]*/, int32_t m, int32_t n, int32_t *swaps, int32_t *nswaps,
+                      int32_t *rows_out);
+
+/* Test-error-pattern table, FS_OSD/convention_osd.py:13-47 (generate_teps, query_boundary):
+ * all supports of weight 0..order over k positions, each weight class in lexicographic
+ * order stably re-sorted by descending index sum.  supports: [count][3] uint8, 0xFF padded
+ * (NULL = only return the count).  boundaries: [order+1] cumulative counts (may be NULL).
+ * Returns the number of patterns or a negative error.  order <= 3.                        */
+int64_t ldpc_tep_table(int32_t k, int32_t order, uint8_t *supports, int64_t *boundaries);
+
+/* ---------------------------------------------------------------------------------------
+ * Device context: uploads the packed H/G, Tanner-graph tables and TEP tables of one code
+ * to one GPU.  Immutable after creation; one ctx per device; decode calls on distinct
+ * streams may run concurrently.
+ * ------------------------------------------------------------------------------------- */
+int ldpc_ctx_create(const ldpc_code *code, int32_t device, ldpc_ctx **out);
+void ldpc_ctx_destroy(ldpc_ctx *ctx);
+/* which NMS kernel LDPC_NMS_AUTO resolves to for this code (LDPC_NMS_GENERIC / _QC16) */
+int ldpc_ctx_nms_kernel(const ldpc_ctx *ctx);
+
+/* ---------------------------------------------------------------------------------------
+ * Normalised min-sum BP, fixed T flooding iterations, no early stop.
+ * Replaces Decoder_Layer.call / belief_propagation_op / compute_vc / compute_cv2 /
+ * marginalize, Ldpc_128_testing/ms_test.py:99-242, and the hard decision + syndrome of
+ * Decoding_model.get_eval :39,:45.
+ *   d_llr     [B][n] f32 channel values (BPSK 0 -> +1, unscaled)
+ *   alpha     host [T] effective check normalisers = softplus(stored weight) (:207-208);
+ *             NMS-1 passes T copies of one value
+ *   w_in/w_out effective bit weights of NMS-2/3 (:127-131, :222-225); 1.0f for NMS-1
+ *   d_soft    [B][n] f32 posterior after iteration T (nullable)
+ *   d_traj    [T][B][n] f32 posterior after iterations 1..T (nullable; the reference's
+ *             soft_output_list without its slot 0, which is d_llr itself)
+ *   d_hard    [B][ceil(n/64)] u64 packed hard decisions (soft > 0 ? 0 : 1) (nullable)
+ *   d_fail    [B] u8, 1 = non-zero syndrome (nullable)
+ * ------------------------------------------------------------------------------------- */
+int ldpc_nms_decode(ldpc_ctx *ctx, const float *d_llr, int64_t B, int32_t T, const float *alpha, float w_in,
+                    float w_out, float *d_soft, float *d_traj, uint64_t *d_hard, uint8_t *d_fail, int32_t kernel,
+                    void *stream);
+
+/* Error statistics, Decoding_model.get_eval, ms_test.py:36-54.
+ * d_counts[5] += {frames, frames_in_error, bit_errors, undetected, syndrome_failures}.
+ * The caller zeroes d_counts; d_fail may be NULL (then undetected/syndrome are not counted). */
+int ldpc_eval_counts(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_label_bits, const uint8_t *d_fail,
+                     int64_t B, int64_t *d_counts, void *stream);
+
+/* Stream compaction of the failed-frame flags, the `tf.where(syndrome != 0)` of
+ * ms_test.py:51: d_index[0..count) = ascending frame numbers with d_flag != 0.
+ * d_index: [B] i32, d_count: [1] i32.                                                     */
+int ldpc_compact(ldpc_ctx *ctx, const uint8_t *d_flag, int64_t B, int32_t *d_index, int32_t *d_count,
+                 void *stream);
+
+/* Bit (un)packing between the reference's one-integer-per-bit labels and packed words.
+ * elem_size: bytes per element of d_bits (1 = u8, 4 = i32, 8 = i64).                      */
+int ldpc_pack_bits(ldpc_ctx *ctx, const void *d_bits /*[B][n]*/, int32_t elem_size, int64_t B,
+                   uint64_t *d_words /*[B][ceil(n/64)]*/, void *stream);
+int ldpc_unpack_bits(ldpc_ctx *ctx, const uint64_t *d_words, int64_t B, void *d_bits, int32_t elem_size,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * OSD (n = 128, k = 64 codes).  Frames are addressed as d_y[ d_index ? d_index[f] : f ].
+ * If d_count is non-NULL the number of frames is min(*d_count, F) read ON THE DEVICE (so a
+ * compaction can feed the OSD without a host round trip); F is then the capacity.
+ * ------------------------------------------------------------------------------------- */
+
+/* Per-frame GF(2) elimination on the device: full_gf2elim, PB_OSD/pb_testing.py:231-266.
+ * d_rows_in/out: [F][64][2] u64 (row r of frame f, columns 0..127); d_swaps: [F][64][2] u8
+ * recorded (j, col) pairs; d_nswaps: [F] i32.                                              */
+int ldpc_osd_ge(ldpc_ctx *ctx, const uint64_t *d_rows_in, int64_t F, uint64_t *d_rows_out, uint8_t *d_swaps,
+                int32_t *d_nswaps, void *stream);
+
+/* OSD front end: swapped_info + identify_mrb, PB_OSD/pb_testing.py:268-320
+ * (reliability sort, column permutation of G, elimination, MRB/LRB bookkeeping).
+ *   d_perm   [F][128] u8 : original bit index at primed position p (pi_1 o pi_2)
+ *   d_parity [F][64] u64 : row r of P' in G' = [I | P']  (bit c = P'[r][c])
+ *   d_nswaps [F] i32 (nullable)                                                            */
+int ldpc_osd_front(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                   uint8_t *d_perm, uint64_t *d_parity, int32_t *d_nswaps, void *stream);
+
+typedef struct ldpc_osd_params {
+    int32_t order;       /* 0..3                                                          */
+    int32_t algo;        /* LDPC_OSD_*                                                    */
+    float snr_db;        /* PB-OSD: noise_variance = 10^(-snr/10), pb_testing.py:50-52     */
+    float fs_beta;       /* FS-OSD beta, Main_FS_OSD.py:20 (0.1)                          */
+    float fs_tau_e;      /* FS-OSD floor(d_min-1)/2 as the reference evaluates it (6.5)    */
+    float fs_tau_psc;    /* FS-OSD tau_psc, FS_OSD/globalmap.py:50 (30)                    */
+    int32_t fs_reference_quirk; /* 1: keep optimal_codeword un-updated on a tau_e hit (fs_testing.py:145) */
+    int32_t reserved;
+} ldpc_osd_params;
+
+/* Ordered-statistics decoding of F frames (front end + search).
+ *   d_cw      [F][2] u64  best codeword, ORIGINAL bit order
+ *   d_metric  [F] f32     its weighted Hamming distance  sum_p (c_p xor h_p) |y_p|
+ *   d_best    [F] i32     index of the winning TEP in the reference's table order
+ *                         (conventional), or its rank in visit order (FS/PB)
+ *   d_ntep    [F] i32     number of TEPs evaluated
+ * Any of d_metric/d_best/d_ntep may be NULL.                                              */
+int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                    const ldpc_osd_params *params, uint64_t *d_cw, float *d_metric, int32_t *d_best,
+                    int32_t *d_ntep, void *stream);
+
+/* OSD statistics against labels: d_counts[3] += {frames, frames_wrong, teps_total}.
+ * (the success test of convention_osd.py:65-66 / pb_testing.py:158 / fs_testing.py:162)   */
+int ldpc_osd_counts(ldpc_ctx *ctx, const uint64_t *d_cw, const uint64_t *d_label_bits, const int32_t *d_index,
+                    const int32_t *d_count, const int32_t *d_ntep, int64_t F, int64_t *d_counts, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_OSD_H */

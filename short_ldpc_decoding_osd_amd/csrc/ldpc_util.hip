@@ -1,0 +1,225 @@
+// Small streaming kernels around the decoders: error statistics, failed-frame compaction,
+// bit (un)packing.  All are HBM-bound byte movers; they read/write every byte once with
+// coalesced accesses and reduce in registers / LDS before touching an atomic.
+//
+// Reference (paths relative to LDPC_128/): Ldpc_128_testing/ms_test.py:36-54 (get_eval),
+// :51 (failure index), Ldpc_128_testing/data_generating.py / read_TFdata.py (labels are one
+// int64 per bit).
+#include "ldpc_internal.h"
+
+namespace ldpc {
+
+// ---------------------------------------------------------------------------------------
+// get_eval counters.  One thread per frame; per-wave reduction by shuffles, one atomic set
+// per wave.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void eval_counts_kernel(const unsigned long long *__restrict__ hard,
+                                                          const unsigned long long *__restrict__ label,
+                                                          const unsigned char *__restrict__ fail, long long B,
+                                                          int words, unsigned long long *__restrict__ counts)
+{
+    unsigned long long ferr = 0, berr = 0, und = 0, sf = 0, cnt = 0;
+    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < B; f += (long long)gridDim.x * blockDim.x) {
+        int e = 0;
+        for (int w = 0; w < words; ++w) e += __popcll(hard[f * words + w] ^ label[f * words + w]);
+        const int bad = fail ? fail[f] != 0 : 0;
+        cnt += 1; berr += e; ferr += e != 0; sf += bad; und += (fail && !bad && e != 0);
+    }
+    cnt = wave_sum(cnt); ferr = wave_sum(ferr); berr = wave_sum(berr); und = wave_sum(und); sf = wave_sum(sf);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[0], cnt); atomicAdd(&counts[1], ferr); atomicAdd(&counts[2], berr);
+        atomicAdd(&counts[3], und); atomicAdd(&counts[4], sf);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Ordered compaction: blocks of kChunk flags.  Pass 1 writes one count per block; pass 2
+// lets every block add up the counts of the blocks before it (<= a few hundred values),
+// redo its local scan and scatter ascending frame numbers.  The last block writes the total.
+// ---------------------------------------------------------------------------------------
+constexpr int kChunk = 2048;  // flags per block: 256 threads x 8
+
+__device__ __forceinline__ unsigned flags8(const unsigned char *flag, long long base, long long B)
+{
+    unsigned bits = 0;
+    if (base + 8 <= B) {
+        unsigned long long v = *reinterpret_cast<const unsigned long long *>(flag + base);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bits |= (unsigned)(((v >> (8 * i)) & 0xFF) != 0) << i;
+    } else {
+        for (int i = 0; i < 8 && base + i < B; ++i) bits |= (unsigned)(flag[base + i] != 0) << i;
+    }
+    return bits;
+}
+
+__global__ __launch_bounds__(256) void compact_count_kernel(const unsigned char *__restrict__ flag, long long B,
+                                                            int *__restrict__ blocksum)
+{
+    __shared__ int part[4];
+    const long long base = (long long)blockIdx.x * kChunk + threadIdx.x * 8;
+    int c = base < B ? __popc(flags8(flag, base, B)) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void compact_scatter_kernel(const unsigned char *__restrict__ flag, long long B,
+                                                              const int *__restrict__ blocksum,
+                                                              int *__restrict__ index, int *__restrict__ count)
+{
+    __shared__ int wsum[4];
+    __shared__ int s_base;
+    // offset of this block = sum of the counts of all earlier blocks
+    int acc = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) acc += blocksum[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const int block_base = s_base;
+    __syncthreads();
+
+    const long long base = (long long)blockIdx.x * kChunk + threadIdx.x * 8;
+    const unsigned bits = base < B ? flags8(flag, base, B) : 0;
+    const int mine = __popc(bits);
+    // exclusive scan over the 256 threads: in-wave inclusive scan, then wave offsets
+    int incl = mine;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+    int pos = block_base + woff + incl - mine;
+    for (int i = 0; i < 8; ++i)
+        if ((bits >> i) & 1) index[pos++] = (int)(base + i);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *count = block_base + woff + incl;
+}
+
+// ---------------------------------------------------------------------------------------
+// bit packing: one wavefront packs 64 bits per step with a ballot
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_bits_kernel(const T *__restrict__ bits, long long B, int n, int words,
+                                                        unsigned long long *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long total = B * words;
+    for (long long t = wave; t < total; t += (long long)gridDim.x * 4) {
+        const long long f = t / words;
+        const int v = (int)(t % words) * 64 + lane;
+        const unsigned long long m = __ballot(v < n && (bits[f * n + v] & 1));
+        if (lane == 0) out[t] = m;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_bits_kernel(const unsigned long long *__restrict__ in, long long B,
+                                                          int n, int words, T *__restrict__ bits)
+{
+    const long long total = B * n;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long f = t / n;
+        const int v = (int)(t % n);
+        bits[t] = (T)((in[f * words + (v >> 6)] >> (v & 63)) & 1);
+    }
+}
+
+static unsigned grid_for(long long items, int per_block, unsigned cap = 4096)
+{
+    long long g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (unsigned)(g < cap ? g : cap);
+}
+
+}  // namespace ldpc
+
+using namespace ldpc;
+
+extern "C" {
+
+int ldpc_eval_counts(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_label, const uint8_t *d_fail,
+                     int64_t B, int64_t *d_counts, void *stream)
+{
+    if (!ctx || !d_hard || !d_label || !d_counts || B < 0) return fail(LDPC_E_ARG, "ldpc_eval_counts: bad arguments");
+    if (B == 0) return LDPC_OK;
+    const int words = (ctx->code.n + 63) / 64;
+    hipLaunchKernelGGL(eval_counts_kernel, dim3(grid_for(B, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned long long *>(d_hard),
+                       reinterpret_cast<const unsigned long long *>(d_label), d_fail, (long long)B, words,
+                       reinterpret_cast<unsigned long long *>(d_counts));
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+int ldpc_compact(ldpc_ctx *ctx, const uint8_t *d_flag, int64_t B, int32_t *d_index, int32_t *d_count, void *stream)
+{
+    if (!ctx || !d_flag || !d_index || !d_count || B < 0 || B > 0x7FFFFFFFLL)
+        return fail(LDPC_E_ARG, "ldpc_compact: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) { LDPC_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return LDPC_OK; }
+    const int64_t blocks = (B + kChunk - 1) / kChunk;
+    if (blocks > ctx->blocksum_cap)
+        return fail(LDPC_E_UNSUPPORTED, "ldpc_compact: B=%lld exceeds the context's scratch (%lld frames)", (long long)B,
+                    (long long)ctx->blocksum_cap * kChunk);
+    hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_flag, (long long)B,
+                       ctx->d_blocksum);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_flag, (long long)B,
+                       ctx->d_blocksum, d_index, d_count);
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+int ldpc_pack_bits(ldpc_ctx *ctx, const void *d_bits, int32_t elem_size, int64_t B, uint64_t *d_words, void *stream)
+{
+    if (!ctx || !d_bits || !d_words || B < 0) return fail(LDPC_E_ARG, "ldpc_pack_bits: bad arguments");
+    if (B == 0) return LDPC_OK;
+    const int n = ctx->code.n, words = (n + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    auto *out = reinterpret_cast<unsigned long long *>(d_words);
+    const dim3 g(grid_for(B * words, 4, 8192)), b(256);
+    switch (elem_size) {
+    case 1: hipLaunchKernelGGL(pack_bits_kernel<unsigned char>, g, b, 0, st, (const unsigned char *)d_bits, (long long)B, n, words, out); break;
+    case 4: hipLaunchKernelGGL(pack_bits_kernel<int>, g, b, 0, st, (const int *)d_bits, (long long)B, n, words, out); break;
+    case 8: hipLaunchKernelGGL(pack_bits_kernel<long long>, g, b, 0, st, (const long long *)d_bits, (long long)B, n, words, out); break;
+    default: return fail(LDPC_E_ARG, "ldpc_pack_bits: elem_size %d (want 1, 4 or 8)", elem_size);
+    }
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+int ldpc_unpack_bits(ldpc_ctx *ctx, const uint64_t *d_words, int64_t B, void *d_bits, int32_t elem_size, void *stream)
+{
+    if (!ctx || !d_bits || !d_words || B < 0) return fail(LDPC_E_ARG, "ldpc_unpack_bits: bad arguments");
+    if (B == 0) return LDPC_OK;
+    const int n = ctx->code.n, words = (n + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    auto *in = reinterpret_cast<const unsigned long long *>(d_words);
+    const dim3 g(grid_for(B * n, 256, 8192)), b(256);
+    switch (elem_size) {
+    case 1: hipLaunchKernelGGL(unpack_bits_kernel<unsigned char>, g, b, 0, st, in, (long long)B, n, words, (unsigned char *)d_bits); break;
+    case 4: hipLaunchKernelGGL(unpack_bits_kernel<int>, g, b, 0, st, in, (long long)B, n, words, (int *)d_bits); break;
+    case 8: hipLaunchKernelGGL(unpack_bits_kernel<long long>, g, b, 0, st, in, (long long)B, n, words, (long long *)d_bits); break;
+    default: return fail(LDPC_E_ARG, "ldpc_unpack_bits: elem_size %d (want 1, 4 or 8)", elem_size);
+    }
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+}  // extern "C"
