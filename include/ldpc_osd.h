@@ -140,6 +140,11 @@ int ldpc_unpack_bits(ldpc_ctx *ctx, const uint64_t *d_words, int64_t B, void *d_
  * compaction can feed the OSD without a host round trip); F is then the capacity.
  * ------------------------------------------------------------------------------------- */
 
+/* Pre-size the context's OSD workspace (1.5 KiB per frame: permutation + reduced parity rows)
+ * for up to max_frames frames per ldpc_osd_decode call.  Decode calls grow it on demand, which
+ * allocates -- reserve first when the calls are to be captured into a hipGraph.             */
+int ldpc_osd_reserve(ldpc_ctx *ctx, int64_t max_frames);
+
 /* Per-frame GF(2) elimination on the device: full_gf2elim, PB_OSD/pb_testing.py:231-266.
  * d_rows_in/out: [F][64][2] u64 (row r of frame f, columns 0..127); d_swaps: [F][64][2] u8
  * recorded (j, col) pairs; d_nswaps: [F] i32.                                              */

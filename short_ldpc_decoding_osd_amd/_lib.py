@@ -18,7 +18,7 @@ SYMBOLS = (
     "ldpc_code_get_H", "ldpc_code_get_G", "ldpc_gf2elim_host", "ldpc_tep_table",
     "ldpc_ctx_create", "ldpc_ctx_destroy", "ldpc_ctx_nms_kernel",
     "ldpc_nms_decode", "ldpc_eval_counts", "ldpc_compact", "ldpc_pack_bits", "ldpc_unpack_bits",
-    "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_decode", "ldpc_osd_counts",
+    "ldpc_osd_reserve", "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_decode", "ldpc_osd_counts",
 )
 
 NMS_AUTO, NMS_GENERIC, NMS_QC16 = 0, 1, 2
@@ -70,6 +70,7 @@ def load():
         "ldpc_compact": (C.c_int, [vp, vp, i64, vp, vp, vp]),
         "ldpc_pack_bits": (C.c_int, [vp, vp, i32, i64, vp, vp]),
         "ldpc_unpack_bits": (C.c_int, [vp, vp, i64, vp, i32, vp]),
+        "ldpc_osd_reserve": (C.c_int, [vp, i64]),
         "ldpc_osd_ge": (C.c_int, [vp, vp, i64, vp, vp, vp, vp]),
         "ldpc_osd_front": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp]),
         "ldpc_osd_decode": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(OsdParams), vp, vp, vp, vp, vp]),

@@ -75,7 +75,7 @@ int ldpc_nms_decode(ldpc_ctx *ctx, const float *d_llr, int64_t B, int32_t T, con
                     float w_out, float *d_soft, float *d_traj, uint64_t *d_hard, uint8_t *d_fail, int32_t kernel,
                     void *stream)
 {
-    if (!ctx || !d_llr || B < 0) return fail(LDPC_E_ARG, "ldpc_nms_decode: bad arguments");
+    if (!ctx || B < 0 || (!d_llr && B > 0)) return fail(LDPC_E_ARG, "ldpc_nms_decode: bad arguments");
     if (T < 0 || T > kMaxIters) return fail(LDPC_E_ARG, "ldpc_nms_decode: T=%d outside 0..%d", T, kMaxIters);
     if (T > 0 && !alpha) return fail(LDPC_E_ARG, "ldpc_nms_decode: alpha is NULL");
     if (B == 0) return LDPC_OK;

@@ -58,6 +58,7 @@ struct ldpc_ctx {
     int64_t blocksum_cap = 0;
     bool dpp_ror_up = true;        // probed: row_ror:n moves data towards higher lanes
     bool osd_ok = false;
+    void *osd_state = nullptr;     // ldpc::OsdState (TEP table sizes, front-end workspace)
 };
 
 namespace ldpc {

@@ -1,13 +1,539 @@
-// placeholder -- replaced by the OSD kernels
+// Ordered-statistics decoding kernels for (128,64) codes on gfx950 (MI355X).
+//
+// Reference (paths relative to LDPC_128/ of the reference):
+//   swapped_info / identify_mrb / full_gf2elim   PB_OSD/pb_testing.py:231-320 (== FS_OSD/fs_testing.py:233-322)
+//   generate_teps / convention_osd_main           FS_OSD/convention_osd.py:13-76
+//
+// One frame per wavefront, no MFMA (bit and compare work).  Two kernels:
+//
+//   osd_front_kernel   reliability sort (rank sort of |y|, ties -> lower index), gather of the
+//                      G columns in sorted order, GF(2) Gauss-Jordan with the reference's pivot
+//                      rule, MRB/LRB bookkeeping.  The matrix lives COLUMN-major in registers:
+//                      lane p holds columns p and p+64 as two 64-bit words (bit = row), so the
+//                      column gather is one load per lane, a pivot step is a handful of
+//                      wave-uniform scalars (v_readlane / ballot / s_ff1) plus ~10 VALU ops, row
+//                      exchanges only touch a lane-resident row map and column exchanges move
+//                      two lanes.  Output: perm (original bit at each primed position) and the
+//                      rows of P' (G' = [I | P']) after a 64x64 bit transpose through lane
+//                      shuffles.
+//   osd_search_kernel  conventional order-p search over the reference's TEP table: per frame a
+//                      byte-indexed LUT of partial |y'| sums in LDS (8 x 256 floats), each lane
+//                      evaluates one TEP per round: parity word = d0 ^ P'[i] ^ P'[j] ..., metric
+//                      = flipped-MRB weights + 8 LUT terms in a FIXED order (the canonical order
+//                      the oracle uses, see oracle/np_oracle.py weighted_distance), first minimum.
 #include "ldpc_internal.h"
-using namespace ldpc;
+
 namespace ldpc {
-int osd_ctx_init(ldpc_ctx *) { return LDPC_OK; }
-void osd_ctx_release(ldpc_ctx *) {}
+
+typedef unsigned long long u64;
+
+constexpr int kOsdN = 128, kOsdK = 64;
+
+// ---------------------------------------------------------------------------------------
+// wave-level helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 readlane64(u64 v, int lane)
+{
+    unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, lane);
+    unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+    return ((u64)hi << 32) | lo;
 }
+
+__device__ __forceinline__ u64 shfl64(u64 v, int src)
+{
+    unsigned lo = __shfl((int)(unsigned)v, src, 64);
+    unsigned hi = __shfl((int)(unsigned)(v >> 32), src, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// 64x64 bit transpose across the wavefront: in: lane a holds bits b; out: lane b holds bits a
+template <int S>
+__device__ __forceinline__ u64 transpose_stage(u64 x, int lane)
+{
+    constexpr u64 m = S == 32 ? 0x00000000FFFFFFFFull : S == 16 ? 0x0000FFFF0000FFFFull : S == 8 ? 0x00FF00FF00FF00FFull
+                    : S == 4 ? 0x0F0F0F0F0F0F0F0Full : S == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+    const u64 p = shfl64(x, lane ^ S);
+    return (lane & S) ? (((p >> S) & m) | (x & ~m)) : ((x & m) | ((p & m) << S));
+}
+
+__device__ __forceinline__ u64 transpose64(u64 x, int lane)
+{
+    x = transpose_stage<32>(x, lane);
+    x = transpose_stage<16>(x, lane);
+    x = transpose_stage<8>(x, lane);
+    x = transpose_stage<4>(x, lane);
+    x = transpose_stage<2>(x, lane);
+    x = transpose_stage<1>(x, lane);
+    return x;
+}
+
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------
+// Gauss-Jordan over GF(2), column-major in registers (full_gf2elim, pb_testing.py:231-266).
+//   C1/C2 : columns lane / lane+64, bit = PHYSICAL row
+//   rho   : lane l = logical row l -> physical row (row exchanges only permute this map)
+//   idx1/2: the reference's index_order entry travelling with each column (:276-281)
+// For i = j = 0..63:  first logical row >= i with a 1 in column i becomes the pivot (:238-245);
+// if there is none, column i is exchanged with the first column >= i in which logical row i has
+// a 1 and the pair is recorded (:251-256); then column i is cleared in every other row (:258-262).
+// Returns the number of column exchanges, or -1 for a rank-deficient matrix.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1, int &idx2, int lane,
+                                          unsigned char *swaps /* LDS or global [64][2], may be null */)
+{
+    int nsw = 0;
+    for (int i = 0; i < kOsdK; ++i) {
+        u64 cj = readlane64(C1, i);
+        const u64 ge_i = ~0ull << i;
+        u64 bal = __ballot((cj >> rho) & 1) & ge_i;
+        int r;
+        if (bal == 0) {
+            const int pri = __builtin_amdgcn_readlane(rho, i);
+            const u64 b1 = __ballot((C1 >> pri) & 1) & ge_i;
+            int col;
+            if (b1) col = __builtin_ctzll(b1);
+            else {
+                const u64 b2 = __ballot((C2 >> pri) & 1);
+                if (b2 == 0) return -1;
+                col = 64 + __builtin_ctzll(b2);
+            }
+            // (select form on purpose: branching on col < 64 makes the compiler spill C1/C2 to scratch)
+            const int cl = col & 63;
+            const bool lo = col < 64;
+            const u64 cc1 = readlane64(C1, cl), cc2 = readlane64(C2, cl);
+            const int ic1 = __builtin_amdgcn_readlane(idx1, cl), ic2 = __builtin_amdgcn_readlane(idx2, cl);
+            const u64 cc = lo ? cc1 : cc2;
+            const int ic = lo ? ic1 : ic2;
+            const int ii = __builtin_amdgcn_readlane(idx1, i);
+            const bool hit = lane == cl;
+            C1 = (hit && lo) ? cj : C1;
+            idx1 = (hit && lo) ? ii : idx1;
+            C2 = (hit && !lo) ? cj : C2;
+            idx2 = (hit && !lo) ? ii : idx2;
+            C1 = (lane == i) ? cc : C1;
+            idx1 = (lane == i) ? ic : idx1;
+            if (swaps && lane == 0) { swaps[2 * nsw] = (unsigned char)i; swaps[2 * nsw + 1] = (unsigned char)col; }
+            ++nsw;
+            cj = cc;
+            r = i;
+        } else {
+            r = __builtin_ctzll(bal);
+        }
+        const int pr = __builtin_amdgcn_readlane(rho, r);
+        if (r != i) {
+            const int pi = __builtin_amdgcn_readlane(rho, i);
+            if (lane == i) rho = pr;
+            if (lane == r) rho = pi;
+        }
+        const u64 e = cj & ~(1ull << pr);
+        if ((C1 >> pr) & 1) C1 ^= e;
+        if ((C2 >> pr) & 1) C2 ^= e;
+    }
+    return nsw;
+}
+
+// ---------------------------------------------------------------------------------------
+// ldpc_osd_ge: elimination of caller-supplied matrices (row-major in, row-major out)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void osd_ge_kernel(const u64 *__restrict__ rows_in, long long F,
+                                                     u64 *__restrict__ rows_out, unsigned char *__restrict__ swaps,
+                                                     int *__restrict__ nswaps)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (long long f = wave; f < F; f += (long long)gridDim.x * 4) {
+        const u64 *src = rows_in + f * 128;
+        u64 C1 = transpose64(src[lane * 2], lane);      // row r, columns 0..63  -> column lane, bit r
+        u64 C2 = transpose64(src[lane * 2 + 1], lane);
+        int rho = lane, idx1 = lane, idx2 = lane + 64;
+        const int ns = ge_columns(C1, C2, rho, idx1, idx2, lane, swaps ? swaps + f * 128 : nullptr);
+        // back to row-major, logical row order: lane = physical row after the transpose
+        const u64 R1 = transpose64(C1, lane), R2 = transpose64(C2, lane);
+        rows_out[f * 128 + lane * 2] = shfl64(R1, rho);
+        rows_out[f * 128 + lane * 2 + 1] = shfl64(R2, rho);
+        if (nswaps && lane == 0) nswaps[f] = ns;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// OSD front end
+// ---------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) FrontLds {
+    int abits[128];          // |y| as integer keys
+    u64 colbuf[64];          // parity columns in primed order
+    unsigned mask[4];        // 128-bit membership mask of the MRB indices
+    unsigned char pi1[128];  // sorted position -> original bit
+    unsigned char rowsrc[64];
+};
+
+__device__ __forceinline__ int below_mask(const unsigned (&m)[4], int x)
+{
+    // number of set bits of the 128-bit mask strictly below position x
+    int c = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int t = x - 32 * d;
+        const unsigned bm = t <= 0 ? 0u : (t >= 32 ? 0xFFFFFFFFu : ((1u << t) - 1u));
+        c += __popc(m[d] & bm);
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void osd_front_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                        const int *__restrict__ count, long long F,
+                                                        const u64 *__restrict__ Gcols,
+                                                        unsigned char *__restrict__ perm_out,
+                                                        u64 *__restrict__ parity_out, int *__restrict__ nswaps)
+{
+    __shared__ FrontLds lds[4];
+    const int lane = threadIdx.x & 63;
+    FrontLds &L = lds[threadIdx.x >> 6];
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+
+    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+        const long long src = index ? index[f] : f;
+        // ---- reliability sort: rank of each |y| in descending order, ties -> lower index ------
+        const int a1 = __float_as_int(y[src * 128 + lane]) & 0x7FFFFFFF;
+        const int a2 = __float_as_int(y[src * 128 + 64 + lane]) & 0x7FFFFFFF;
+        L.abits[lane] = a1;
+        L.abits[lane + 64] = a2;
+        wave_fence();
+        int r1 = 0, r2 = 0;
+        // "u before v"  <=>  a_u > a_v  or  (a_u == a_v and u < v)   (integer order == float order for |y|)
+#pragma unroll 4
+        for (int u4 = 0; u4 < 32; ++u4) {
+            const int4 kq = *reinterpret_cast<const int4 *>(&L.abits[u4 * 4]);
+            const int kk[4] = {kq.x, kq.y, kq.z, kq.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u = u4 * 4 + q;
+                r1 += (kk[q] > a1) || (kk[q] == a1 && u < lane);
+                r2 += (kk[q] > a2) || (kk[q] == a2 && u < lane + 64);
+            }
+        }
+        L.pi1[r1] = (unsigned char)lane;
+        L.pi1[r2] = (unsigned char)(lane + 64);
+        if (lane < 4) L.mask[lane] = 0;
+        wave_fence();
+        // ---- G with columns in sorted order, column-major ------------------------------------
+        u64 C1 = Gcols[L.pi1[lane]];
+        u64 C2 = Gcols[L.pi1[lane + 64]];
+        int rho = lane, idx1 = lane, idx2 = lane + 64;
+        const int ns = ge_columns(C1, C2, rho, idx1, idx2, lane, nullptr);
+        // ---- identify_mrb bookkeeping (pb_testing.py:276-304) --------------------------------
+        atomicOr(&L.mask[idx1 >> 5], 1u << (idx1 & 31));
+        wave_fence();
+        const unsigned m[4] = {L.mask[0], L.mask[1], L.mask[2], L.mask[3]};
+        const int rankM = below_mask(m, idx1);         // new MRB position of slot `lane`
+        const int rankL = idx2 - below_mask(m, idx2);  // new parity column of slot `lane`
+        perm_out[f * 128 + rankM] = L.pi1[idx1];
+        perm_out[f * 128 + 64 + rankL] = L.pi1[idx2];
+        L.colbuf[rankL] = C2;
+        L.rowsrc[rankM] = (unsigned char)rho;          // pivot of MRB slot `lane` is physical row rho
+        wave_fence();
+        const u64 R = transpose64(L.colbuf[lane], lane);   // lane = physical row, bit = parity column
+        parity_out[f * 64 + lane] = shfl64(R, L.rowsrc[lane]);
+        if (nswaps && lane == 0) nswaps[f] = ns;
+        wave_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// conventional order-p search (convention_osd_main, convention_osd.py:49-76)
+// ---------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) SearchLds {
+    float lut[8][256];   // lut[b][v] = sum of |y'[64+8b+t]| over the set bits t of v, ascending t
+    u64 P[64];           // rows of P'
+    float w[128];        // |y'|
+    u64 cw[2];           // codeword being assembled in original bit order
+    unsigned char perm[128];
+};
+
+__device__ __forceinline__ float tep_cost(const SearchLds &L, float mrb, u64 D)
+{
+    float acc = mrb;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc = acc + L.lut[b][(D >> (8 * b)) & 0xFF];
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void osd_search_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                         const int *__restrict__ count, long long F,
+                                                         const unsigned char *__restrict__ perm_in,
+                                                         const u64 *__restrict__ parity_in,
+                                                         const uchar4 *__restrict__ teps, int ntep,
+                                                         u64 *__restrict__ cw_out, float *__restrict__ metric_out,
+                                                         int *__restrict__ best_out, int *__restrict__ ntep_out)
+{
+    __shared__ SearchLds lds[4];
+    const int lane = threadIdx.x & 63;
+    SearchLds &L = lds[threadIdx.x >> 6];
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+
+    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+        const long long src = index ? index[f] : f;
+        // primed-order values: y'[p] = y[perm[p]]
+        const int o1 = perm_in[f * 128 + lane], o2 = perm_in[f * 128 + 64 + lane];
+        const float y1 = y[src * 128 + o1], y2 = y[src * 128 + o2];
+        const u64 Prow = parity_in[f * 64 + lane];
+        L.perm[lane] = (unsigned char)o1;
+        L.perm[lane + 64] = (unsigned char)o2;
+        L.w[lane] = __builtin_fabsf(y1);
+        L.w[lane + 64] = __builtin_fabsf(y2);
+        L.P[lane] = Prow;
+        if (lane < 2) L.cw[lane] = 0;
+        const u64 hm = __ballot(!(y1 > 0.0f));   // hard decisions of the MRB  (y' > 0 ? 0 : 1, :54)
+        const u64 hp = __ballot(!(y2 > 0.0f));   // ... of the parity part
+        wave_fence();
+        // byte LUTs: lane (b = lane/8, g = lane%8) fills entries v = 32 g + r, r = 0..31
+        {
+            const int b = lane >> 3, g = lane & 7;
+            float wt[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) wt[t] = L.w[64 + 8 * b + t];
+            float R[32];
+            R[0] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+#pragma unroll
+                for (int r = 1 << t; r < (2 << t); ++r) R[r] = R[r - (1 << t)] + wt[t];
+            const float h5 = (g & 1) ? wt[5] : 0.0f, h6 = (g & 2) ? wt[6] : 0.0f, h7 = (g & 4) ? wt[7] : 0.0f;
+            float *dst = &L.lut[b][g * 32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) dst[r] = ((R[r] + h5) + h6) + h7;
+        }
+        // order-0 parity discrepancy: d0 = (u0 . P') ^ h_parity ; XOR-reduce the selected rows
+        u64 sel = ((hm >> lane) & 1) ? Prow : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sel ^= shfl64(sel, lane ^ off);
+        const u64 d0 = sel ^ hp;
+        wave_fence();
+        // ---- scan the TEP table, one TEP per lane per round; strict '<' keeps the first minimum
+        float best = __builtin_inff();
+        int bestt = 0x7FFFFFFF;
+        u64 bestD = 0, bestE = 0;
+        for (int t = lane; t < ntep; t += 64) {
+            const uchar4 s = teps[t];
+            u64 D = d0, E = 0;
+            float mrb = 0.0f;
+            if (s.w > 0) { D ^= L.P[s.x]; E |= 1ull << s.x; mrb = L.w[s.x]; }
+            if (s.w > 1) { D ^= L.P[s.y]; E |= 1ull << s.y; mrb = mrb + L.w[s.y]; }
+            if (s.w > 2) { D ^= L.P[s.z]; E |= 1ull << s.z; mrb = mrb + L.w[s.z]; }
+            const float c = tep_cost(L, mrb, D);
+            if (c < best) { best = c; bestt = t; bestD = D; bestE = E; }
+        }
+        // ---- wave argmin on (cost, table index) ------------------------------------------------
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float oc = __shfl(best, lane ^ off, 64);
+            const int ot = __shfl(bestt, lane ^ off, 64);
+            const u64 oD = shfl64(bestD, lane ^ off), oE = shfl64(bestE, lane ^ off);
+            if (oc < best || (oc == best && ot < bestt)) { best = oc; bestt = ot; bestD = oD; bestE = oE; }
+        }
+        // ---- winning codeword back to the original bit order -----------------------------------
+        const u64 mrb_bits = hm ^ bestE, par_bits = bestD ^ hp;
+        if ((mrb_bits >> lane) & 1) atomicOr(&L.cw[o1 >> 6], 1ull << (o1 & 63));
+        if ((par_bits >> lane) & 1) atomicOr(&L.cw[o2 >> 6], 1ull << (o2 & 63));
+        wave_fence();
+        if (lane < 2) cw_out[f * 2 + lane] = L.cw[lane];
+        if (lane == 0) {
+            if (metric_out) metric_out[f] = best;
+            if (best_out) best_out[f] = bestt;
+            if (ntep_out) ntep_out[f] = ntep;
+        }
+        wave_fence();
+    }
+}
+
+__global__ __launch_bounds__(256) void osd_counts_kernel(const u64 *__restrict__ cw, const u64 *__restrict__ label,
+                                                         const int *__restrict__ index, const int *__restrict__ count,
+                                                         const int *__restrict__ ntep, long long F,
+                                                         u64 *__restrict__ counts)
+{
+    __shared__ u64 part[4][3];
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    u64 n = 0, wrong = 0, teps = 0;
+    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < nframes; f += (long long)gridDim.x * blockDim.x) {
+        const long long src = index ? index[f] : f;
+        n += 1;
+        wrong += (cw[f * 2] != label[src * 2]) || (cw[f * 2 + 1] != label[src * 2 + 1]);
+        teps += ntep ? (u64)ntep[f] : 0ull;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_down(n, off, 64); wrong += __shfl_down(wrong, off, 64); teps += __shfl_down(teps, off, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[wave][0] = n; part[wave][1] = wrong; part[wave][2] = teps; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        atomicAdd(&counts[threadIdx.x], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------
+// context pieces: G columns, TEP table (order <= 3), front-end workspace
+// ---------------------------------------------------------------------------------------
+struct OsdState {
+    int64_t ntep[4] = {0, 0, 0, 0};
+    unsigned char *d_perm = nullptr;  // workspace [cap][128]
+    u64 *d_parity = nullptr;          // workspace [cap][64]
+    int64_t cap = 0;
+};
+
+static OsdState *state(ldpc_ctx *ctx) { return reinterpret_cast<OsdState *>(ctx->osd_state); }
+
+int osd_ctx_init(ldpc_ctx *ctx)
+{
+    const ldpc_code &c = ctx->code;
+    ctx->osd_ok = false;
+    if (c.n != kOsdN || c.k != kOsdK) return LDPC_OK;  // OSD entry points will report UNSUPPORTED
+    std::vector<u64> cols(kOsdN, 0);
+    for (int r = 0; r < kOsdK; ++r)
+        for (int v = 0; v < kOsdN; ++v)
+            if (c.G[(size_t)r * kOsdN + v]) cols[v] |= 1ull << r;
+    LDPC_HIP(hipMalloc((void **)&ctx->d_Gcols, sizeof(u64) * kOsdN));
+    LDPC_HIP(hipMemcpy(ctx->d_Gcols, cols.data(), sizeof(u64) * kOsdN, hipMemcpyHostToDevice));
+    // one table for order 3; orders 0..2 are its prefixes (weight classes are concatenated)
+    OsdState *st = new OsdState();
+    ctx->osd_state = st;
+    int64_t bounds[4];
+    const int64_t total = tep_table(kOsdK, 3, nullptr, bounds);
+    std::vector<uint8_t> sup((size_t)total * 3), packed((size_t)total * 4);
+    tep_table(kOsdK, 3, sup.data(), nullptr);
+    for (int64_t t = 0; t < total; ++t) {
+        int w = 0;
+        for (int q = 0; q < 3; ++q) { packed[4 * t + q] = sup[3 * t + q] == 0xFF ? 0 : sup[3 * t + q]; w += sup[3 * t + q] != 0xFF; }
+        packed[4 * t + 3] = (uint8_t)w;
+    }
+    for (int o = 0; o < 4; ++o) st->ntep[o] = bounds[o];
+    LDPC_HIP(hipMalloc((void **)&ctx->d_tep, packed.size()));
+    LDPC_HIP(hipMemcpy(ctx->d_tep, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    ctx->osd_ok = true;
+    return LDPC_OK;
+}
+
+void osd_ctx_release(ldpc_ctx *ctx)
+{
+    (void)hipFree(ctx->d_Gcols);
+    (void)hipFree(ctx->d_tep);
+    if (OsdState *st = state(ctx)) {
+        (void)hipFree(st->d_perm);
+        (void)hipFree(st->d_parity);
+        delete st;
+    }
+    ctx->osd_state = nullptr;
+}
+
+static int reserve(ldpc_ctx *ctx, int64_t frames)
+{
+    OsdState *st = state(ctx);
+    if (frames <= st->cap) return LDPC_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)cs;
+    (void)hipFree(st->d_perm); (void)hipFree(st->d_parity);
+    st->d_perm = nullptr; st->d_parity = nullptr; st->cap = 0;
+    if (hipMalloc((void **)&st->d_perm, (size_t)frames * 128) != hipSuccess ||
+        hipMalloc((void **)&st->d_parity, (size_t)frames * 64 * sizeof(u64)) != hipSuccess)
+        return fail(LDPC_E_NOMEM, "OSD workspace for %lld frames could not be allocated", (long long)frames);
+    st->cap = frames;
+    return LDPC_OK;
+}
+
+static unsigned osd_grid(int64_t F)
+{
+    // persistent grid: enough blocks to fill 256 CUs a few times over, frames are strided over waves
+    int64_t want = (F + 3) / 4;
+    return (unsigned)(want < 1 ? 1 : (want < 4096 ? want : 4096));
+}
+
+}  // namespace ldpc
+
+using namespace ldpc;
+
 extern "C" {
-int ldpc_osd_ge(ldpc_ctx *, const uint64_t *, int64_t, uint64_t *, uint8_t *, int32_t *, void *) { return fail(LDPC_E_UNSUPPORTED, "not built yet"); }
-int ldpc_osd_front(ldpc_ctx *, const float *, const int32_t *, const int32_t *, int64_t, uint8_t *, uint64_t *, int32_t *, void *) { return fail(LDPC_E_UNSUPPORTED, "not built yet"); }
-int ldpc_osd_decode(ldpc_ctx *, const float *, const int32_t *, const int32_t *, int64_t, const ldpc_osd_params *, uint64_t *, float *, int32_t *, int32_t *, void *) { return fail(LDPC_E_UNSUPPORTED, "not built yet"); }
-int ldpc_osd_counts(ldpc_ctx *, const uint64_t *, const uint64_t *, const int32_t *, const int32_t *, const int32_t *, int64_t, int64_t *, void *) { return fail(LDPC_E_UNSUPPORTED, "not built yet"); }
+
+int ldpc_osd_reserve(ldpc_ctx *ctx, int64_t max_frames)
+{
+    if (!ctx || max_frames < 0) return fail(LDPC_E_ARG, "ldpc_osd_reserve: bad arguments");
+    if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
+    return reserve(ctx, max_frames);
 }
+
+int ldpc_osd_ge(ldpc_ctx *ctx, const uint64_t *d_rows_in, int64_t F, uint64_t *d_rows_out, uint8_t *d_swaps,
+                int32_t *d_nswaps, void *stream)
+{
+    if (!ctx || F < 0 || (F > 0 && (!d_rows_in || !d_rows_out))) return fail(LDPC_E_ARG, "ldpc_osd_ge: bad arguments");
+    if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
+    if (F == 0) return LDPC_OK;
+    hipLaunchKernelGGL(osd_ge_kernel, dim3(osd_grid(F)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const u64 *>(d_rows_in), (long long)F, reinterpret_cast<u64 *>(d_rows_out), d_swaps,
+                       d_nswaps);
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+int ldpc_osd_front(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                   uint8_t *d_perm, uint64_t *d_parity, int32_t *d_nswaps, void *stream)
+{
+    if (!ctx || F < 0 || (F > 0 && (!d_y || !d_perm || !d_parity))) return fail(LDPC_E_ARG, "ldpc_osd_front: bad arguments");
+    if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
+    if (F == 0) return LDPC_OK;
+    hipLaunchKernelGGL(osd_front_kernel, dim3(osd_grid(F)), dim3(256), 0, (hipStream_t)stream, d_y, d_index, d_count,
+                       (long long)F, reinterpret_cast<const u64 *>(ctx->d_Gcols), d_perm, reinterpret_cast<u64 *>(d_parity),
+                       d_nswaps);
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                    const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric, int32_t *d_best, int32_t *d_ntep,
+                    void *stream)
+{
+    if (!ctx || !p || F < 0 || (F > 0 && (!d_y || !d_cw))) return fail(LDPC_E_ARG, "ldpc_osd_decode: bad arguments");
+    if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
+    if (p->order < 0 || p->order > 3) return fail(LDPC_E_ARG, "ldpc_osd_decode: order %d outside 0..3", p->order);
+    if (p->algo != LDPC_OSD_CONVENTIONAL)
+        return fail(LDPC_E_UNSUPPORTED, "ldpc_osd_decode: search algorithm %d is not built yet (conventional = 0 is)", p->algo);
+    if (F == 0) return LDPC_OK;
+    OsdState *st = state(ctx);
+    if (F > st->cap) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(LDPC_E_NOMEM, "ldpc_osd_decode: workspace holds %lld frames, %lld needed; call ldpc_osd_reserve before capturing", (long long)st->cap, (long long)F);
+        int rc = reserve(ctx, F);
+        if (rc) return rc;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(osd_front_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
+                       reinterpret_cast<const u64 *>(ctx->d_Gcols), st->d_perm, st->d_parity, (int *)nullptr);
+    hipLaunchKernelGGL(osd_search_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
+                       st->d_perm, st->d_parity, reinterpret_cast<const uchar4 *>(ctx->d_tep), (int)st->ntep[p->order],
+                       reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+int ldpc_osd_counts(ldpc_ctx *ctx, const uint64_t *d_cw, const uint64_t *d_label_bits, const int32_t *d_index,
+                    const int32_t *d_count, const int32_t *d_ntep, int64_t F, int64_t *d_counts, void *stream)
+{
+    if (!ctx || F < 0 || !d_counts || (F > 0 && (!d_cw || !d_label_bits))) return fail(LDPC_E_ARG, "ldpc_osd_counts: bad arguments");
+    if (F == 0) return LDPC_OK;
+    int64_t g = (F + 1023) / 1024;
+    hipLaunchKernelGGL(osd_counts_kernel, dim3((unsigned)(g < 128 ? g : 128)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const u64 *>(d_cw), reinterpret_cast<const u64 *>(d_label_bits), d_index, d_count,
+                       d_ntep, (long long)F, reinterpret_cast<u64 *>(d_counts));
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+}  // extern "C"

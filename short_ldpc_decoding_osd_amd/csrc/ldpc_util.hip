@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void eval_counts_kernel(const unsigned long lo
                                                           const unsigned char *__restrict__ fail, long long B,
                                                           int words, unsigned long long *__restrict__ counts)
 {
+    __shared__ unsigned long long part[4][5];
     unsigned long long ferr = 0, berr = 0, und = 0, sf = 0, cnt = 0;
     for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < B; f += (long long)gridDim.x * blockDim.x) {
         int e = 0;
@@ -33,10 +34,15 @@ __global__ __launch_bounds__(256) void eval_counts_kernel(const unsigned long lo
         cnt += 1; berr += e; ferr += e != 0; sf += bad; und += (fail && !bad && e != 0);
     }
     cnt = wave_sum(cnt); ferr = wave_sum(ferr); berr = wave_sum(berr); und = wave_sum(und); sf = wave_sum(sf);
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&counts[0], cnt); atomicAdd(&counts[1], ferr); atomicAdd(&counts[2], berr);
-        atomicAdd(&counts[3], und); atomicAdd(&counts[4], sf);
+        part[wave][0] = cnt; part[wave][1] = ferr; part[wave][2] = berr; part[wave][3] = und; part[wave][4] = sf;
     }
+    __syncthreads();
+    // one atomic per counter per block (a few hundred in all): contended same-line atomics
+    // serialise at the memory side, so keep them rare
+    if (threadIdx.x < 5)
+        atomicAdd(&counts[threadIdx.x], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -160,7 +166,7 @@ int ldpc_eval_counts(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_la
     if (!ctx || !d_hard || !d_label || !d_counts || B < 0) return fail(LDPC_E_ARG, "ldpc_eval_counts: bad arguments");
     if (B == 0) return LDPC_OK;
     const int words = (ctx->code.n + 63) / 64;
-    hipLaunchKernelGGL(eval_counts_kernel, dim3(grid_for(B, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(eval_counts_kernel, dim3(grid_for(B, 1024, 128)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned long long *>(d_hard),
                        reinterpret_cast<const unsigned long long *>(d_label), d_fail, (long long)B, words,
                        reinterpret_cast<unsigned long long *>(d_counts));
@@ -170,7 +176,7 @@ int ldpc_eval_counts(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_la
 
 int ldpc_compact(ldpc_ctx *ctx, const uint8_t *d_flag, int64_t B, int32_t *d_index, int32_t *d_count, void *stream)
 {
-    if (!ctx || !d_flag || !d_index || !d_count || B < 0 || B > 0x7FFFFFFFLL)
+    if (!ctx || !d_count || B < 0 || B > 0x7FFFFFFFLL || (B > 0 && (!d_flag || !d_index)))
         return fail(LDPC_E_ARG, "ldpc_compact: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) { LDPC_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return LDPC_OK; }
