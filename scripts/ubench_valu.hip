@@ -8,8 +8,11 @@
 
 #define REP16(x) x x x x x x x x x x x x x x x x
 
+#ifndef NUM_VGPR
+#define NUM_VGPR 24
+#endif
 template <int OP>
-__global__ __launch_bounds__(256) void k(float *out, int iters, unsigned long long *clk)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(NUM_VGPR))) void k(float *out, int iters, unsigned long long *clk)
 {
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float b = out[threadIdx.x & 63];
@@ -56,6 +59,10 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, unsigned long lo
                                "v_mov_b32_dpp %4, %0 row_ror:3 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %1 row_ror:3 row_mask:0xf bank_mask:0xf\n"
                                "v_mov_b32_dpp %6, %2 row_ror:3 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %3 row_ror:3 row_mask:0xf bank_mask:0xf\n"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+        } else if constexpr (OP == 10) {  // NMS-like mix: sub_dpp, med3, min|.|, xor, cmp+cndmask, xor, bfi, add_dpp
+            REP16(asm volatile("v_sub_f32_dpp %0, %4, %0 row_ror:3 row_mask:0xf bank_mask:0xf\n v_med3_f32 %1, %1, %8, |%0|\n v_min_f32 %2, %2, |%0|\n v_xor_b32 %3, %3, %0\n"
+                               "v_cmp_gt_f32 s[20:21], |%0|, %2\n v_cndmask_b32 %5, %1, %2, s[20:21]\n v_xor_b32 %6, %3, %0\n v_bfi_b32 %7, %8, %5, %6\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "s20", "s21");)
         } else if constexpr (OP == 9) {  // ds_bpermute_b32 (LDS crossbar shuffle)
             REP16(asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n"
                                "ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)\n"
@@ -71,7 +78,7 @@ template <int OP>
 void run(const char *name, float *d, unsigned long long *dclk)
 {
     const int iters = 200;
-    for (int wps = 1; wps <= 8; wps *= 2) {
+    for (int wps : {1, 2, 3, 4, 5, 6, 8}) {
         int blocks = 256 * wps;  // 4 waves per block -> wps waves per SIMD on 256 CUs
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
@@ -108,5 +115,6 @@ int main()
     run<7>("v_add_f32 dependent chain", d, dclk);
     run<8>("v_mov_b32_dpp row_ror", d, dclk);
     run<9>("ds_bpermute_b32", d, dclk);
+    run<10>("NMS-like mix (dependent)", d, dclk);
     return 0;
 }
