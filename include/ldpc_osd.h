@@ -86,6 +86,11 @@ int ldpc_gf2elim_host(int32_t *M /*[m][n]*/, int32_t m, int32_t n, int32_t *swap
  * Returns the number of patterns or a negative error.  order <= 3.                        */
 int64_t ldpc_tep_table(int32_t k, int32_t order, uint8_t *supports, int64_t *boundaries);
 
+/* FS-OSD visit order of one weight class, FS_OSD/fs_testing.py:32-49 (generate_sequential_teps):
+ * lexicographic combinations of range(k) with the indicator vector reversed (support {k-1-p}).
+ * supports: [C(k,weight)][3] uint8 ascending positions, 0xFF padded (NULL = only the count).   */
+int64_t ldpc_tep_table_fs(int32_t k, int32_t weight, uint8_t *supports);
+
 /* ---------------------------------------------------------------------------------------
  * Device context: uploads the packed H/G, Tanner-graph tables and TEP tables of one code
  * to one GPU.  Immutable after creation; one ctx per device; decode calls on distinct

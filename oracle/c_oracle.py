@@ -45,6 +45,9 @@ def lib():
         L.orc_tep_table.restype = C.c_int64
         L.orc_conv_osd_batch.argtypes = [i32p, f32p, u8p, C.c_int64, C.c_int, i32p, f32p, u8p]
         L.orc_conv_osd_batch.restype = C.c_int
+        L.orc_fs_osd_batch.argtypes = [i32p, f32p, u8p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, i32p, f32p,
+                                       u8p, u8p]
+        L.orc_fs_osd_batch.restype = C.c_int
         _lib = L
     return _lib
 
@@ -140,3 +143,23 @@ def conv_osd(G, y, labels, order):
         raise RuntimeError("orc_conv_osd_batch failed")
     return dict(best=info[:, 0].copy(), phase=info[:, 1].copy(), correct=info[:, 2].astype(bool),
                 teps_size=int(info[0, 3]) if F else 0, nswaps=info[:, 4].copy(), metric=metric, codeword=cw)
+
+
+def fs_osd(G, y, labels, order, beta=0.1, tau_e=6.5, tau_psc=30.0):
+    """FS-OSD on [F,128] original-order frames (fs_testing.py:129-161).  Returns dict of arrays;
+    ``*_ref`` follow the reference's ``optimal_codeword`` (quirk kept), ``*_hit`` the tau_e winner."""
+    G = _i32(G)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    F = y.shape[0]
+    lab = np.ascontiguousarray(labels, dtype=np.uint8) if labels is not None else None
+    info = np.empty((F, 5), dtype=np.int32)
+    met = np.empty((F, 2), dtype=np.float32)
+    cw_ref = np.empty((F, 128), dtype=np.uint8)
+    cw_hit = np.empty((F, 128), dtype=np.uint8)
+    rc = lib().orc_fs_osd_batch(_p(G, C.c_int32), _p(y, C.c_float), _p(lab, C.c_uint8), F, order, beta, tau_e, tau_psc,
+                                _p(info, C.c_int32), _p(met, C.c_float), _p(cw_ref, C.c_uint8), _p(cw_hit, C.c_uint8))
+    if rc:
+        raise RuntimeError("orc_fs_osd_batch failed")
+    return dict(num_teps=info[:, 0].copy(), hit=info[:, 1].astype(bool), best_index=info[:, 2].copy(),
+                correct_ref=info[:, 3].astype(bool), correct_hit=info[:, 4].astype(bool), metric_ref=met[:, 0].copy(),
+                metric_hit=met[:, 1].copy(), codeword_ref=cw_ref, codeword_hit=cw_hit)

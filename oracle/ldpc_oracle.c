@@ -453,3 +453,83 @@ int orc_conv_osd_batch(const int32_t *G, const float *y, const uint8_t *labels, 
     free(teps);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* FS-OSD (fs_testing.py:22-64, 129-161), one frame, original-order y.                     */
+/* TEP visit order inside weight w (generate_sequential_teps :32-49): lexicographic        */
+/* combinations of range(k) with the indicator reversed -> supports {k-1-p}.               */
+/* out_i32: {num_teps, hit(0/1), winner visit index (ref), correct_ref, correct_hit}        */
+/* out_f32: {metric_ref, metric_hit}; cw_ref / cw_hit: [128] original order (cw_hit = cw_ref */
+/* when there was no tau_e hit beyond order 0).                                             */
+/* ------------------------------------------------------------------------------------ */
+static int next_comb(int *c, int w, int k)
+{
+    int q = w - 1;
+    while (q >= 0 && c[q] == k - w + q) --q;
+    if (q < 0) return 0;
+    ++c[q];
+    for (int z = q + 1; z < w; ++z) c[z] = c[z - 1] + 1;
+    return 1;
+}
+
+int orc_fs_osd(const int32_t *G, const float *y, const uint8_t *label, int order, float beta, float tau_e,
+               float tau_psc, int32_t *out_i32, float *out_f32, uint8_t *cw_ref, uint8_t *cw_hit)
+{
+    int32_t perm[128], Gp[64 * 128];
+    float yp[128];
+    osd_frame f;
+    if (orc_osd_front(G, 64, 128, y, perm, Gp, NULL, NULL)) return -1;
+    for (int p = 0; p < 128; ++p) yp[p] = y[perm[p]];
+    frame_prepare(&f, yp, Gp);
+    float bounds[3];
+    for (int i = 0; i < order; ++i) {
+        float acc = 0.0f;
+        for (int t = 64 - (i + 1); t < 64; ++t) acc = acc + f.w[t];
+        bounds[i] = acc;
+    }
+    const float beta_term = (float)((double)beta * 64.0);
+    uint64_t bestD = f.d0, bestE = 0, hitD = 0, hitE = 0;
+    float best = frame_cost(&f, 0.0f, f.d0), hitc = 0.0f;
+    int ntep = 1, hit = 0, bestidx = 0;
+    int hd0 = __builtin_popcountll(f.d0);
+    if (!((float)hd0 < tau_e)) {
+        for (int j = 0; j < order && !hit; ++j) {
+            if (!(bounds[j] + beta_term < best)) break;
+            int w = j + 1, c[3] = {0, 1, 2};
+            do {
+                ++ntep;
+                uint64_t D = f.d0, E = 0;
+                float mrb = 0.0f;
+                for (int q = w - 1; q >= 0; --q) { /* ascending position = reversed combination */
+                    int p = 63 - c[q];
+                    D ^= f.P[p]; E |= 1ull << p; mrb = (q == w - 1) ? f.w[p] : mrb + f.w[p];
+                }
+                float cost = frame_cost(&f, mrb, D);
+                int hd = w + __builtin_popcountll(D);
+                if ((float)hd < tau_e) { hit = 1; hitD = D; hitE = E; hitc = cost; break; }
+                if ((float)hd < tau_psc && cost < best) { best = cost; bestD = D; bestE = E; bestidx = ntep - 1; }
+            } while (next_comb(c, w, 64));
+        }
+    }
+    uint8_t a[128], b[128];
+    codeword_to_original(&f, f.hm ^ bestE, bestD, perm, a);
+    if (hit) codeword_to_original(&f, f.hm ^ hitE, hitD, perm, b); else memcpy(b, a, 128);
+    out_i32[0] = ntep; out_i32[1] = hit; out_i32[2] = bestidx;
+    out_i32[3] = label ? memcmp(a, label, 128) == 0 : 0;
+    out_i32[4] = label ? memcmp(b, label, 128) == 0 : 0;
+    out_f32[0] = best; out_f32[1] = hit ? hitc : best;
+    if (cw_ref) memcpy(cw_ref, a, 128);
+    if (cw_hit) memcpy(cw_hit, b, 128);
+    return 0;
+}
+
+int orc_fs_osd_batch(const int32_t *G, const float *y, const uint8_t *labels, int64_t F, int order, float beta,
+                     float tau_e, float tau_psc, int32_t *out_i32 /*[F][5]*/, float *out_f32 /*[F][2]*/,
+                     uint8_t *cw_ref /*[F][128]*/, uint8_t *cw_hit /*[F][128]*/)
+{
+    int rc = 0;
+    for (int64_t i = 0; i < F && !rc; ++i)
+        rc = orc_fs_osd(G, y + i * 128, labels ? labels + i * 128 : NULL, order, beta, tau_e, tau_psc, out_i32 + 5 * i,
+                        out_f32 + 2 * i, cw_ref ? cw_ref + i * 128 : NULL, cw_hit ? cw_hit + i * 128 : NULL);
+    return rc;
+}

@@ -415,3 +415,71 @@ def convention_osd(yp, labelp, Gp, order, teps=None):
     return dict(correct=correct, teps_size=int(teps.shape[0]), phase=phase, best_index=best,
                 metric=cost[best], codeword=cand[best], costs=cost,
                 exact_best=int(np.argmin(disc.astype(np.float64).dot(w.astype(np.float64)))))
+
+
+# --------------------------------------------------------------------------------------
+# FS-OSD:  FS_OSD/fs_testing.py:22-64, 129-161
+# --------------------------------------------------------------------------------------
+
+
+def fs_tep_lists(k, order):
+    """``generate_sequential_teps`` (fs_testing.py:32-49): for w = 1..order every combination of
+    range(k) in lexicographic order with the indicator vector reversed (:45), i.e. support
+    {k-1-p}.  Returns a list (per weight) of lists of ascending support tuples."""
+    out = []
+    for w in range(1, order + 1):
+        out.append([tuple(sorted(k - 1 - p for p in c)) for c in itertools.combinations(range(k), w)])
+    return out
+
+
+def fs_osd_frame(yp, labelp, Gp, order, beta=0.1, tau_e=6.5, tau_psc=30.0):
+    """One frame of ``fs_osd`` (fs_testing.py:129-161) in the primed domain.
+
+    Returns dict(codeword_ref, metric_ref = what the reference keeps in ``optimal_codeword`` /
+    ``w_dmin`` (:148-152), codeword_hit / metric_hit = the candidate that triggered the tau_e stop
+    (appended to ``optimal_list`` but never copied to ``optimal_codeword``, :144-146 -- the quirk
+    SURVEY A.4 describes), num_teps (:141), fail_ref = the reference's failure test (:162)).
+    """
+    yp = np.asarray(yp, dtype=F32)
+    k, n = Gp.shape
+    w = np.abs(yp)
+    hard = np.where(yp > 0, 0, 1).astype(np.int64)
+
+    def one_tep(support):                                   # one_tep_compare :51-64
+        mrb = hard[:k].copy()
+        for p in support:
+            mrb[p] ^= 1
+        cw = mrb.dot(Gp) % 2
+        disc = (cw + hard) % 2
+        return int(disc.sum()), cw, _weighted_distance_k(disc, w, k)
+
+    # acquire_pnc_boundary :22-30 -- float32 running sums of the (i+1) least reliable MRB values
+    bounds = []
+    for i in range(order):
+        acc = F32(0)
+        for t in range(k - (i + 1), k):
+            acc = F32(acc + w[t])
+        bounds.append(acc)
+    beta_term = F32(beta * (n - k))                         # :138, python float -> f32 in the TF add
+    hd, best_cw, w_dmin = one_tep(())                       # all-zero TEP :131
+    num_teps = 1
+    hit_cw, hit_metric = None, None
+    if not hd < tau_e:                                      # :133-135
+        for j in range(order):
+            if F32(bounds[j] + beta_term) < w_dmin:         # :139
+                stop = False
+                for support in fs_tep_lists(k, j + 1)[j]:
+                    num_teps += 1                           # :141
+                    hd, cw, wd = one_tep(support)
+                    if hd < tau_e:                          # :143-146
+                        hit_cw, hit_metric, stop = cw, wd, True
+                        break
+                    if hd < tau_psc and wd < w_dmin:        # :147-152
+                        w_dmin, best_cw = wd, cw
+                if stop:
+                    break
+            else:                                           # :155-158
+                break
+    fail_ref = None if labelp is None else bool(np.any(best_cw != np.asarray(labelp)))
+    return dict(codeword_ref=best_cw, metric_ref=w_dmin, codeword_hit=hit_cw, metric_hit=hit_metric,
+                num_teps=num_teps, fail_ref=fail_ref)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libldpcosd.so")
 SYMBOLS = (
     "ldpc_last_error", "ldpc_abi_version",
     "ldpc_code_from_alist", "ldpc_code_from_dense", "ldpc_code_destroy", "ldpc_code_dims",
-    "ldpc_code_get_H", "ldpc_code_get_G", "ldpc_gf2elim_host", "ldpc_tep_table",
+    "ldpc_code_get_H", "ldpc_code_get_G", "ldpc_gf2elim_host", "ldpc_tep_table", "ldpc_tep_table_fs",
     "ldpc_ctx_create", "ldpc_ctx_destroy", "ldpc_ctx_nms_kernel",
     "ldpc_nms_decode", "ldpc_eval_counts", "ldpc_compact", "ldpc_pack_bits", "ldpc_unpack_bits",
     "ldpc_osd_reserve", "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_decode", "ldpc_osd_counts",
@@ -61,6 +61,7 @@ def load():
         "ldpc_code_get_G": (C.c_int, [vp, pi32]),
         "ldpc_gf2elim_host": (C.c_int, [pi32, i32, i32, pi32, pi32, pi32]),
         "ldpc_tep_table": (i64, [i32, i32, C.POINTER(C.c_uint8), pi64]),
+        "ldpc_tep_table_fs": (i64, [i32, i32, C.POINTER(C.c_uint8)]),
         "ldpc_ctx_create": (C.c_int, [vp, i32, C.POINTER(vp)]),
         "ldpc_ctx_destroy": (None, [vp]),
         "ldpc_ctx_nms_kernel": (C.c_int, [vp]),

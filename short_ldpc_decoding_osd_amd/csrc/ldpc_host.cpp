@@ -211,6 +211,28 @@ int64_t tep_table(int k, int order, uint8_t *supports, int64_t *boundaries)
     return total;
 }
 
+// FS-OSD visit order of ONE weight class (generate_sequential_teps, FS_OSD/fs_testing.py:32-49):
+// lexicographic combinations of range(k) with the indicator vector reversed, i.e. support {k-1-p}.
+// supports: [count][3] ascending positions, 0xFF padded.  Returns C(k, w).
+int64_t tep_table_fs(int k, int w, uint8_t *supports)
+{
+    if (k < 1 || k > 255 || w < 1 || w > 3) return fail(LDPC_E_ARG, "tep_table_fs: k=%d w=%d", k, w);
+    const int64_t total = binom(k, w);
+    if (!supports) return total;
+    int c[3] = {0, 1, 2};
+    for (int64_t t = 0; t < total; ++t) {
+        uint8_t *dst = supports + 3 * t;
+        dst[0] = dst[1] = dst[2] = 0xFF;
+        for (int q = 0; q < w; ++q) dst[w - 1 - q] = (uint8_t)(k - 1 - c[q]);  // reversed => ascending
+        int q = w - 1;
+        while (q >= 0 && c[q] == k - w + q) --q;
+        if (q < 0) break;
+        ++c[q];
+        for (int z = q + 1; z < w; ++z) c[z] = c[z - 1] + 1;
+    }
+    return total;
+}
+
 }  // namespace ldpc
 
 using namespace ldpc;
@@ -308,5 +330,7 @@ int64_t ldpc_tep_table(int32_t k, int32_t order, uint8_t *supports, int64_t *bou
 {
     return tep_table(k, order, supports, boundaries);
 }
+
+int64_t ldpc_tep_table_fs(int32_t k, int32_t weight, uint8_t *supports) { return tep_table_fs(k, weight, supports); }
 
 }  // extern "C"

@@ -67,6 +67,7 @@ namespace ldpc {
 int gf2elim(int32_t *M, int m, int n, std::vector<int32_t> *swaps);  // returns rows left
 int build_code(ldpc_code &c);  // fills G, graph tables, qc flag from c.H/m/n
 int64_t tep_table(int k, int order, uint8_t *supports, int64_t *boundaries);
+int64_t tep_table_fs(int k, int w, uint8_t *supports);
 
 // launchers (one per .hip file)
 int launch_nms(ldpc_ctx *ctx, const float *d_llr, int64_t B, int T, const float *alpha, float w_in, float w_out,

@@ -214,7 +214,7 @@ __device__ __forceinline__ void var_sums(const float (&cv)[32], int j, float (&S
 
 // One block row of check nodes: lane j is check (BR, j).
 template <int BR, bool UP>
-__device__ __forceinline__ void check_row(float (&cv)[32], const float (&tot)[8], float a_it)
+__device__ __forceinline__ void check_row(float (&cv)[32], const float (&tot)[8], float a_it, unsigned signv)
 {
     float vc[8];
     // vc = tot[var] - cv ; variable (bc, j + s) sits s lanes above: rotate down by s
@@ -233,10 +233,15 @@ __device__ __forceinline__ void check_row(float (&cv)[32], const float (&tot)[8]
     }
     const float m1s = a_it * __builtin_fminf(m1, 1e30f);
     const float m2s = (m1 == 0.0f) ? 0.0f : a_it * __builtin_fminf(m2, 1e30f);
+    // fold the row's sign product into both candidates once; per edge only the edge's own sign bit
+    // is XORed in (v_and + v_xor with VGPR operands run at the fast VALU rate on gfx950, v_bfi and
+    // anything with an SGPR/literal operand at half of it: profiles/r01/ubench_valu_issue2.txt)
+    const unsigned sg = sx & signv;
+    const unsigned m1S = __float_as_uint(m1s) ^ sg, m2S = __float_as_uint(m2s) ^ sg;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const float mag = (__builtin_fabsf(vc[t]) > m1) ? m1s : m2s;
-        cv[BR * 8 + t] = __uint_as_float(sign_insert(__float_as_uint(mag), sx ^ __float_as_uint(vc[t])));
+        const unsigned sel = (__builtin_fabsf(vc[t]) > m1) ? m1S : m2S;
+        cv[BR * 8 + t] = __uint_as_float(sel ^ (__float_as_uint(vc[t]) & signv));
     }
 }
 
@@ -276,15 +281,18 @@ __global__ __launch_bounds__(256) void nms_qc16_kernel(const float *__restrict__
 #pragma unroll
     for (int e = 0; e < 32; ++e) cv[e] = 0.0f;
 
+    unsigned signv;  // 0x80000000 held in a VGPR on purpose (see check_row)
+    asm volatile("v_mov_b32 %0, 0x80000000" : "=v"(signv));
     for (int it = 0; it < T; ++it) {
-        const float a_it = alpha.a[it];
+        float a_it;      // alpha[it] copied to a VGPR: VALU ops with an SGPR operand issue at half rate
+        asm volatile("v_mov_b32 %0, %1" : "=v"(a_it) : "s"(alpha.a[it]));
         float tot[8];
 #pragma unroll
         for (int bc = 0; bc < 8; ++bc) tot[bc] = S[bc] + yin[bc];
-        check_row<0, UP>(cv, tot, a_it);
-        check_row<1, UP>(cv, tot, a_it);
-        check_row<2, UP>(cv, tot, a_it);
-        check_row<3, UP>(cv, tot, a_it);
+        check_row<0, UP>(cv, tot, a_it, signv);
+        check_row<1, UP>(cv, tot, a_it, signv);
+        check_row<2, UP>(cv, tot, a_it, signv);
+        check_row<3, UP>(cv, tot, a_it, signv);
         var_sums<UP>(cv, j, S);
         if (traj) {
             float *dst = traj + ((long long)it * B + fl) * 128 + j;

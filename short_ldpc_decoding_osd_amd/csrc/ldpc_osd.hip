@@ -264,6 +264,90 @@ __device__ __forceinline__ float tep_cost(const SearchLds &L, float mrb, u64 D)
     return acc;
 }
 
+// per-frame set-up shared by every search: primed-order values into LDS, hard decisions, byte
+// LUTs, and the parity discrepancy d0 of the order-0 candidate
+struct SearchFrame {
+    u64 hm, hp, d0;   // hard decisions of the MRB / parity part (y' > 0 ? 0 : 1), order-0 discrepancy
+    int o1, o2;       // original bit index of primed positions lane and 64 + lane
+};
+
+__device__ __forceinline__ SearchFrame search_prepare(SearchLds &L, const float *__restrict__ y, long long src,
+                                                      const unsigned char *__restrict__ perm_in,
+                                                      const u64 *__restrict__ parity_in, long long f, int lane)
+{
+    SearchFrame S;
+    S.o1 = perm_in[f * 128 + lane];
+    S.o2 = perm_in[f * 128 + 64 + lane];
+    const float y1 = y[src * 128 + S.o1], y2 = y[src * 128 + S.o2];   // y'[p] = y[perm[p]]
+    const u64 Prow = parity_in[f * 64 + lane];
+    L.perm[lane] = (unsigned char)S.o1;
+    L.perm[lane + 64] = (unsigned char)S.o2;
+    L.w[lane] = __builtin_fabsf(y1);
+    L.w[lane + 64] = __builtin_fabsf(y2);
+    L.P[lane] = Prow;
+    if (lane < 2) L.cw[lane] = 0;
+    S.hm = __ballot(!(y1 > 0.0f));
+    S.hp = __ballot(!(y2 > 0.0f));
+    wave_fence();
+    // byte LUTs: lane (b = lane/8, g = lane%8) fills entries v = 32 g + r, r = 0..31
+    {
+        const int b = lane >> 3, g = lane & 7;
+        float wt[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) wt[t] = L.w[64 + 8 * b + t];
+        float R[32];
+        R[0] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int r = 1 << t; r < (2 << t); ++r) R[r] = R[r - (1 << t)] + wt[t];
+        const float h5 = (g & 1) ? wt[5] : 0.0f, h6 = (g & 2) ? wt[6] : 0.0f, h7 = (g & 4) ? wt[7] : 0.0f;
+        float *dst = &L.lut[b][g * 32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) dst[r] = ((R[r] + h5) + h6) + h7;
+    }
+    // d0 = (u0 . P') ^ h_parity : XOR-reduce the rows selected by the MRB hard decisions
+    u64 sel = ((S.hm >> lane) & 1) ? Prow : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sel ^= shfl64(sel, lane ^ off);
+    S.d0 = sel ^ S.hp;
+    wave_fence();
+    return S;
+}
+
+// candidate (E = flipped MRB positions, D = parity discrepancy) -> codeword in ORIGINAL bit order
+__device__ __forceinline__ void search_finish(SearchLds &L, const SearchFrame &S, u64 E, u64 D, long long f, int lane,
+                                              u64 *__restrict__ cw_out)
+{
+    const u64 mrb_bits = S.hm ^ E, par_bits = D ^ S.hp;
+    if ((mrb_bits >> lane) & 1) atomicOr(&L.cw[S.o1 >> 6], 1ull << (S.o1 & 63));
+    if ((par_bits >> lane) & 1) atomicOr(&L.cw[S.o2 >> 6], 1ull << (S.o2 & 63));
+    wave_fence();
+    if (lane < 2) cw_out[f * 2 + lane] = L.cw[lane];
+    wave_fence();
+}
+
+// one TEP (ascending support s.x < s.y < s.z, weight s.w) -> parity discrepancy, flip mask, MRB weight sum
+__device__ __forceinline__ void tep_apply(const SearchLds &L, uchar4 s, u64 d0, u64 &D, u64 &E, float &mrb)
+{
+    D = d0; E = 0; mrb = 0.0f;
+    if (s.w > 0) { D ^= L.P[s.x]; E |= 1ull << s.x; mrb = L.w[s.x]; }
+    if (s.w > 1) { D ^= L.P[s.y]; E |= 1ull << s.y; mrb = mrb + L.w[s.y]; }
+    if (s.w > 2) { D ^= L.P[s.z]; E |= 1ull << s.z; mrb = mrb + L.w[s.z]; }
+}
+
+// wave arg-min on (cost, index): every lane returns the winner
+__device__ __forceinline__ void wave_argmin(float &best, int &bestt, u64 &bestD, u64 &bestE, int lane)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl(best, lane ^ off, 64);
+        const int ot = __shfl(bestt, lane ^ off, 64);
+        const u64 oD = shfl64(bestD, lane ^ off), oE = shfl64(bestE, lane ^ off);
+        if (oc < best || (oc == best && ot < bestt)) { best = oc; bestt = ot; bestD = oD; bestE = oE; }
+    }
+}
+
 __global__ __launch_bounds__(256) void osd_search_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                          const int *__restrict__ count, long long F,
                                                          const unsigned char *__restrict__ perm_in,
@@ -281,76 +365,110 @@ __global__ __launch_bounds__(256) void osd_search_kernel(const float *__restrict
 
     for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
         const long long src = index ? index[f] : f;
-        // primed-order values: y'[p] = y[perm[p]]
-        const int o1 = perm_in[f * 128 + lane], o2 = perm_in[f * 128 + 64 + lane];
-        const float y1 = y[src * 128 + o1], y2 = y[src * 128 + o2];
-        const u64 Prow = parity_in[f * 64 + lane];
-        L.perm[lane] = (unsigned char)o1;
-        L.perm[lane + 64] = (unsigned char)o2;
-        L.w[lane] = __builtin_fabsf(y1);
-        L.w[lane + 64] = __builtin_fabsf(y2);
-        L.P[lane] = Prow;
-        if (lane < 2) L.cw[lane] = 0;
-        const u64 hm = __ballot(!(y1 > 0.0f));   // hard decisions of the MRB  (y' > 0 ? 0 : 1, :54)
-        const u64 hp = __ballot(!(y2 > 0.0f));   // ... of the parity part
-        wave_fence();
-        // byte LUTs: lane (b = lane/8, g = lane%8) fills entries v = 32 g + r, r = 0..31
-        {
-            const int b = lane >> 3, g = lane & 7;
-            float wt[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) wt[t] = L.w[64 + 8 * b + t];
-            float R[32];
-            R[0] = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 5; ++t)
-#pragma unroll
-                for (int r = 1 << t; r < (2 << t); ++r) R[r] = R[r - (1 << t)] + wt[t];
-            const float h5 = (g & 1) ? wt[5] : 0.0f, h6 = (g & 2) ? wt[6] : 0.0f, h7 = (g & 4) ? wt[7] : 0.0f;
-            float *dst = &L.lut[b][g * 32];
-#pragma unroll
-            for (int r = 0; r < 32; ++r) dst[r] = ((R[r] + h5) + h6) + h7;
-        }
-        // order-0 parity discrepancy: d0 = (u0 . P') ^ h_parity ; XOR-reduce the selected rows
-        u64 sel = ((hm >> lane) & 1) ? Prow : 0ull;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sel ^= shfl64(sel, lane ^ off);
-        const u64 d0 = sel ^ hp;
-        wave_fence();
-        // ---- scan the TEP table, one TEP per lane per round; strict '<' keeps the first minimum
+        const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+        // scan the TEP table, one TEP per lane per round; strict '<' keeps the first minimum
         float best = __builtin_inff();
         int bestt = 0x7FFFFFFF;
         u64 bestD = 0, bestE = 0;
         for (int t = lane; t < ntep; t += 64) {
-            const uchar4 s = teps[t];
-            u64 D = d0, E = 0;
-            float mrb = 0.0f;
-            if (s.w > 0) { D ^= L.P[s.x]; E |= 1ull << s.x; mrb = L.w[s.x]; }
-            if (s.w > 1) { D ^= L.P[s.y]; E |= 1ull << s.y; mrb = mrb + L.w[s.y]; }
-            if (s.w > 2) { D ^= L.P[s.z]; E |= 1ull << s.z; mrb = mrb + L.w[s.z]; }
+            u64 D, E;
+            float mrb;
+            tep_apply(L, teps[t], S.d0, D, E, mrb);
             const float c = tep_cost(L, mrb, D);
             if (c < best) { best = c; bestt = t; bestD = D; bestE = E; }
         }
-        // ---- wave argmin on (cost, table index) ------------------------------------------------
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float oc = __shfl(best, lane ^ off, 64);
-            const int ot = __shfl(bestt, lane ^ off, 64);
-            const u64 oD = shfl64(bestD, lane ^ off), oE = shfl64(bestE, lane ^ off);
-            if (oc < best || (oc == best && ot < bestt)) { best = oc; bestt = ot; bestD = oD; bestE = oE; }
-        }
-        // ---- winning codeword back to the original bit order -----------------------------------
-        const u64 mrb_bits = hm ^ bestE, par_bits = bestD ^ hp;
-        if ((mrb_bits >> lane) & 1) atomicOr(&L.cw[o1 >> 6], 1ull << (o1 & 63));
-        if ((par_bits >> lane) & 1) atomicOr(&L.cw[o2 >> 6], 1ull << (o2 & 63));
-        wave_fence();
-        if (lane < 2) cw_out[f * 2 + lane] = L.cw[lane];
+        wave_argmin(best, bestt, bestD, bestE, lane);
+        search_finish(L, S, bestE, bestD, f, lane, cw_out);
         if (lane == 0) {
             if (metric_out) metric_out[f] = best;
             if (best_out) best_out[f] = bestt;
             if (ntep_out) ntep_out[f] = ntep;
         }
-        wave_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// FS-OSD (fs_osd, FS_OSD/fs_testing.py:129-161): order-by-order scan in the order of
+// generate_sequential_teps (:32-49) with two Hamming-distance rules (one_tep_compare :51-64):
+//   HD < tau_e            -> stop everything (the candidate is appended to optimal_list, :143-146)
+//   HD < tau_psc and a smaller weighted distance -> new best (:147-152)
+// and a lower bound per order: scan weight w only if (sum of the w least reliable MRB |y'|) +
+// beta (n-k) < best so far (:137-139, acquire_pnc_boundary :22-30).  64 TEPs are evaluated per
+// round; the sequential semantics are recovered with a ballot (first tau_e hit) and an arg-min
+// over the lanes before it.  quirk = 1 returns what the reference keeps in `optimal_codeword`
+// (the best BEFORE a tau_e hit), quirk = 0 the tau_e candidate itself.
+// ---------------------------------------------------------------------------------------
+struct FsParams {
+    int order, quirk;
+    float beta_term, tau_e, tau_psc;
+    int cls_off[4], cls_cnt[4];   // weight class w: offset / count inside the FS-ordered table
+};
+
+__global__ __launch_bounds__(256) void osd_fs_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                     const int *__restrict__ count, long long F,
+                                                     const unsigned char *__restrict__ perm_in,
+                                                     const u64 *__restrict__ parity_in,
+                                                     const uchar4 *__restrict__ teps_fs, FsParams P,
+                                                     u64 *__restrict__ cw_out, float *__restrict__ metric_out,
+                                                     int *__restrict__ best_out, int *__restrict__ ntep_out)
+{
+    __shared__ SearchLds lds[4];
+    const int lane = threadIdx.x & 63;
+    SearchLds &L = lds[threadIdx.x >> 6];
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+
+    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+        const long long src = index ? index[f] : f;
+        const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+        float best = tep_cost(L, 0.0f, S.d0);      // all-zero TEP (:131)
+        u64 bestD = S.d0, bestE = 0, hitD = 0, hitE = 0;
+        float hitc = 0.0f;
+        int bestidx = 0, ntep = 1, visited = 1, hitidx = 0;
+        bool hit = false;
+        if (!((float)__popcll(S.d0) < P.tau_e)) {
+            for (int w = 1; w <= P.order && !hit; ++w) {
+                float bsum = 0.0f;                  // w least reliable MRB values, ascending position
+                for (int t = 64 - w; t < 64; ++t) bsum = bsum + L.w[t];
+                if (!(bsum + P.beta_term < best)) break;
+                const int cnt = P.cls_cnt[w];
+                const uchar4 *tab = teps_fs + P.cls_off[w];
+                for (int t0 = 0; t0 < cnt && !hit; t0 += 64) {
+                    const int t = t0 + lane;
+                    const bool valid = t < cnt;
+                    u64 D = 0, E = 0;
+                    float mrb = 0.0f;
+                    if (valid) tep_apply(L, tab[t], S.d0, D, E, mrb);
+                    const float c = tep_cost(L, mrb, D);
+                    const float hd = (float)(w + __popcll(D));
+                    const u64 stop = __ballot(valid && hd < P.tau_e);
+                    const int lim = stop ? __builtin_ctzll(stop) : 64;
+                    const int nvalid = (cnt - t0) < 64 ? (cnt - t0) : 64;
+                    ntep += stop ? lim + 1 : nvalid;
+                    // best among the TEPs visited before the stop that pass the tau_psc rule
+                    float cc = (valid && lane < lim && hd < P.tau_psc) ? c : __builtin_inff();
+                    int ci = lane;
+                    u64 cD = D, cE = E;
+                    wave_argmin(cc, ci, cD, cE, lane);
+                    if (cc < best) { best = cc; bestD = cD; bestE = cE; bestidx = visited + t0 + ci; }
+                    if (stop) {
+                        hit = true;
+                        hitD = readlane64(D, lim); hitE = readlane64(E, lim);
+                        hitc = __shfl(c, lim, 64);
+                        hitidx = visited + t0 + lim;
+                    }
+                }
+                visited += cnt;
+            }
+        }
+        const bool use_hit = hit && !P.quirk;
+        search_finish(L, S, use_hit ? hitE : bestE, use_hit ? hitD : bestD, f, lane, cw_out);
+        if (lane == 0) {
+            if (metric_out) metric_out[f] = use_hit ? hitc : best;
+            if (best_out) best_out[f] = use_hit ? hitidx : bestidx;
+            if (ntep_out) ntep_out[f] = ntep;
+        }
     }
 }
 
@@ -385,6 +503,8 @@ __global__ __launch_bounds__(256) void osd_counts_kernel(const u64 *__restrict__
 // ---------------------------------------------------------------------------------------
 struct OsdState {
     int64_t ntep[4] = {0, 0, 0, 0};
+    uchar4 *d_tep_fs = nullptr;       // FS visit order, weight classes 1..3 back to back
+    int fs_off[4] = {0, 0, 0, 0}, fs_cnt[4] = {0, 0, 0, 0};
     unsigned char *d_perm = nullptr;  // workspace [cap][128]
     u64 *d_parity = nullptr;          // workspace [cap][64]
     int64_t cap = 0;
@@ -418,6 +538,22 @@ int osd_ctx_init(ldpc_ctx *ctx)
     for (int o = 0; o < 4; ++o) st->ntep[o] = bounds[o];
     LDPC_HIP(hipMalloc((void **)&ctx->d_tep, packed.size()));
     LDPC_HIP(hipMemcpy(ctx->d_tep, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    // FS-OSD visit order (generate_sequential_teps, fs_testing.py:32-49), supports stored ascending
+    std::vector<uint8_t> fs;
+    int off = 0;
+    for (int w = 1; w <= 3; ++w) {
+        const int64_t cnt = tep_table_fs(kOsdK, w, nullptr);
+        std::vector<uint8_t> sup3((size_t)cnt * 3);
+        tep_table_fs(kOsdK, w, sup3.data());
+        st->fs_off[w] = off; st->fs_cnt[w] = (int)cnt;
+        for (int64_t t = 0; t < cnt; ++t) {
+            for (int q = 0; q < 3; ++q) fs.push_back(sup3[3 * t + q] == 0xFF ? 0 : sup3[3 * t + q]);
+            fs.push_back((uint8_t)w);
+        }
+        off += (int)cnt;
+    }
+    LDPC_HIP(hipMalloc((void **)&st->d_tep_fs, fs.size()));
+    LDPC_HIP(hipMemcpy(st->d_tep_fs, fs.data(), fs.size(), hipMemcpyHostToDevice));
     ctx->osd_ok = true;
     return LDPC_OK;
 }
@@ -429,6 +565,7 @@ void osd_ctx_release(ldpc_ctx *ctx)
     if (OsdState *st = state(ctx)) {
         (void)hipFree(st->d_perm);
         (void)hipFree(st->d_parity);
+        (void)hipFree(st->d_tep_fs);
         delete st;
     }
     ctx->osd_state = nullptr;
@@ -502,8 +639,8 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
     if (!ctx || !p || F < 0 || (F > 0 && (!d_y || !d_cw))) return fail(LDPC_E_ARG, "ldpc_osd_decode: bad arguments");
     if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
     if (p->order < 0 || p->order > 3) return fail(LDPC_E_ARG, "ldpc_osd_decode: order %d outside 0..3", p->order);
-    if (p->algo != LDPC_OSD_CONVENTIONAL)
-        return fail(LDPC_E_UNSUPPORTED, "ldpc_osd_decode: search algorithm %d is not built yet (conventional = 0 is)", p->algo);
+    if (p->algo != LDPC_OSD_CONVENTIONAL && p->algo != LDPC_OSD_FS)
+        return fail(LDPC_E_UNSUPPORTED, "ldpc_osd_decode: search algorithm %d is not built yet (conventional = 0, FS = 1 are)", p->algo);
     if (F == 0) return LDPC_OK;
     OsdState *st = state(ctx);
     if (F > st->cap) {
@@ -516,9 +653,20 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(osd_front_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
                        reinterpret_cast<const u64 *>(ctx->d_Gcols), st->d_perm, st->d_parity, (int *)nullptr);
-    hipLaunchKernelGGL(osd_search_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
-                       st->d_perm, st->d_parity, reinterpret_cast<const uchar4 *>(ctx->d_tep), (int)st->ntep[p->order],
-                       reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
+    if (p->algo == LDPC_OSD_FS) {
+        FsParams fp;
+        fp.order = p->order; fp.quirk = p->fs_reference_quirk != 0;
+        fp.beta_term = (float)((double)p->fs_beta * (double)(kOsdN - kOsdK));   // fs_testing.py:138
+        fp.tau_e = p->fs_tau_e; fp.tau_psc = p->fs_tau_psc;
+        for (int w = 0; w < 4; ++w) { fp.cls_off[w] = st->fs_off[w]; fp.cls_cnt[w] = st->fs_cnt[w]; }
+        hipLaunchKernelGGL(osd_fs_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
+                           st->d_perm, st->d_parity, st->d_tep_fs, fp, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
+                           d_ntep);
+    } else {
+        hipLaunchKernelGGL(osd_search_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
+                           st->d_perm, st->d_parity, reinterpret_cast<const uchar4 *>(ctx->d_tep), (int)st->ntep[p->order],
+                           reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
+    }
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;
 }

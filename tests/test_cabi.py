@@ -88,3 +88,18 @@ def test_no_gpu_means_loud_failure():
     from short_ldpc_decoding_osd_amd.runtime import Decoder
     with pytest.raises(_lib.LdpcError, match="no CPU path|no GPU"):
         Decoder(Code())
+
+
+def test_fs_tep_order_host():
+    """ldpc_tep_table_fs == generate_sequential_teps (fs_testing.py:32-49)."""
+    from oracle import np_oracle
+    from short_ldpc_decoding_osd_amd import _lib
+    L = _lib.load()
+    lists = np_oracle.fs_tep_lists(64, 2)
+    for w in (1, 2):
+        n = L.ldpc_tep_table_fs(64, w, None)
+        t = np.empty((n, 3), dtype=np.uint8)
+        L.ldpc_tep_table_fs(64, w, t.ctypes.data_as(C.POINTER(C.c_uint8)))
+        assert [tuple(int(x) for x in r if x != 255) for r in t] == lists[w - 1]
+    assert lists[0][:3] == [(63,), (62,), (61,)] and lists[1][:3] == [(62, 63), (61, 63), (60, 63)]
+    assert L.ldpc_tep_table_fs(64, 3, None) == 41664 and L.ldpc_tep_table_fs(64, 4, None) < 0

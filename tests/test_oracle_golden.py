@@ -125,3 +125,27 @@ def test_conv_osd_c_vs_numpy(np_code):
             assert np.array_equal(cw_o, res["codeword"][j])
             assert not (np_code.H.dot(cw_o) % 2).any()
             assert r["exact_best"] == r["best_index"]          # summation order is immaterial here
+
+
+def test_fs_osd_c_vs_numpy(np_code):
+    """FS-OSD restatements agree (fs_testing.py:129-161): TEP counts, kept codeword, tau_e winner."""
+    rng = np.random.default_rng(31)
+    y, cw = np_oracle.make_frames(np_code.G, 2.5, 500, rng)
+    soft = c_oracle.nms(np_code.H, y, 10, 0.669435)
+    _, fail, _ = c_oracle.evaluate(np_code.H, soft, cw)
+    idx = np.flatnonzero(fail)[:30]
+    for order, tau_e in [(1, 6.5), (2, 6.5), (2, 13.5)]:
+        res = c_oracle.fs_osd(np_code.G, y[idx], cw[idx], order, 0.1, tau_e, 30.0)
+        for j, i in enumerate(idx):
+            yp, lp, Gp, perm, _ = np_oracle.swapped_info(y[i], cw[i], np_code.G)
+            o = np_oracle.fs_osd_frame(yp, lp, Gp, order, 0.1, tau_e, 30.0)
+            cwo = np.empty(128, dtype=np.int64)
+            cwo[perm] = o["codeword_ref"]
+            assert o["num_teps"] == res["num_teps"][j]
+            assert np.array_equal(cwo, res["codeword_ref"][j]) and o["metric_ref"] == res["metric_ref"][j]
+            assert (o["codeword_hit"] is not None) == bool(res["hit"][j])
+            assert o["fail_ref"] == (not res["correct_ref"][j])
+            if o["codeword_hit"] is not None:
+                ch = np.empty(128, dtype=np.int64)
+                ch[perm] = o["codeword_hit"]
+                assert np.array_equal(ch, res["codeword_hit"][j]) and o["metric_hit"] == res["metric_hit"][j]
