@@ -173,14 +173,18 @@ typedef struct ldpc_osd_params {
     float fs_tau_psc;    /* FS-OSD tau_psc, FS_OSD/globalmap.py:50 (30)                    */
     int32_t fs_reference_quirk; /* 1: keep optimal_codeword un-updated on a tau_e hit (fs_testing.py:145) */
     int32_t reserved;
+    void *d_aux;         /* optional DEVICE [F][4] i32, PB-OSD statistics per frame: {frontier comparisons
+                            (memory_sum, pb_testing.py:122), suc counter 1 (:138), suc counter 2 (:144),
+                            stop reason 0 = none / 1 = promising rule (:129) / 2 = success rule (:145)} */
 } ldpc_osd_params;
 
 /* Ordered-statistics decoding of F frames (front end + search).
  *   d_cw      [F][2] u64  best codeword, ORIGINAL bit order
  *   d_metric  [F] f32     its weighted Hamming distance  sum_p (c_p xor h_p) |y_p|
  *   d_best    [F] i32     index of the winning TEP in the reference's table order
- *                         (conventional), or its rank in visit order (FS/PB)
- *   d_ntep    [F] i32     number of TEPs evaluated
+ *                         (conventional), or its rank in visit order (FS/PB; 0 = all-zero TEP)
+ *   d_ntep    [F] i32     number of TEPs evaluated (FS: num_teps, fs_testing.py:141; PB: cost_tep_num
+ *                         or N_max when no rule fired, pb_testing.py:152-155)
  * Any of d_metric/d_best/d_ntep may be NULL.                                              */
 int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
                     const ldpc_osd_params *params, uint64_t *d_cw, float *d_metric, int32_t *d_best,

@@ -48,6 +48,12 @@ def lib():
         L.orc_fs_osd_batch.argtypes = [i32p, f32p, u8p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, i32p, f32p,
                                        u8p, u8p]
         L.orc_fs_osd_batch.restype = C.c_int
+        L.orc_pb_osd_batch.argtypes = [i32p, f32p, u8p, C.c_int64, C.c_int, C.c_float, i32p, f32p, u8p]
+        L.orc_pb_osd_batch.restype = C.c_int
+        L.orc_det_expf.argtypes = [C.c_float]
+        L.orc_det_expf.restype = C.c_float
+        L.orc_binom_cdf64.argtypes = [C.c_double, C.POINTER(C.c_double)]
+        L.orc_binom_cdf64.restype = None
         _lib = L
     return _lib
 
@@ -163,3 +169,31 @@ def fs_osd(G, y, labels, order, beta=0.1, tau_e=6.5, tau_psc=30.0):
     return dict(num_teps=info[:, 0].copy(), hit=info[:, 1].astype(bool), best_index=info[:, 2].copy(),
                 correct_ref=info[:, 3].astype(bool), correct_hit=info[:, 4].astype(bool), metric_ref=met[:, 0].copy(),
                 metric_hit=met[:, 1].copy(), codeword_ref=cw_ref, codeword_hit=cw_hit)
+
+
+def pb_osd(G, y, labels, order, snr_db):
+    """PB-OSD on [F,128] original-order frames (pb_testing.py:100-149)."""
+    G = _i32(G)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    F = y.shape[0]
+    lab = np.ascontiguousarray(labels, dtype=np.uint8) if labels is not None else None
+    info = np.empty((F, 7), dtype=np.int32)
+    metric = np.empty(F, dtype=np.float32)
+    cw = np.empty((F, 128), dtype=np.uint8)
+    rc = lib().orc_pb_osd_batch(_p(G, C.c_int32), _p(y, C.c_float), _p(lab, C.c_uint8), F, order, snr_db,
+                                _p(info, C.c_int32), _p(metric, C.c_float), _p(cw, C.c_uint8))
+    if rc:
+        raise RuntimeError("orc_pb_osd_batch failed")
+    return dict(num_teps=info[:, 0].copy(), best_index=info[:, 1].copy(), correct=info[:, 2].astype(bool),
+                comparisons=info[:, 3].copy(), suc1=info[:, 4].copy(), suc2=info[:, 5].copy(), stop=info[:, 6].copy(),
+                metric=metric, codeword=cw)
+
+
+def det_expf(x):
+    return np.array([lib().orc_det_expf(float(v)) for v in np.atleast_1d(x)], dtype=np.float32)
+
+
+def binom_cdf64(p):
+    out = np.empty(65, dtype=np.float64)
+    lib().orc_binom_cdf64(float(p), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out

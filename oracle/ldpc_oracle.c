@@ -533,3 +533,156 @@ int orc_fs_osd_batch(const int32_t *G, const float *y, const uint8_t *labels, in
                         out_f32 + 2 * i, cw_ref ? cw_ref + i * 128 : NULL, cw_hit ? cw_hit + i * 128 : NULL);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* PB-OSD (pb_testing.py:35-41, 100-149, 366-500), one frame, original-order y.            */
+/*                                                                                        */
+/* Float conventions (the reference mixes TF float32 tensors, Python floats and SciPy      */
+/* float64; none of it is pinned by a reference vector -- "parity unpinned"):             */
+/*   c4 = (float)(-4 / 10^(snr/10));  q_p = sigmoid(c4 |y'_p|) in float32 with the         */
+/*   deterministic det_expf below (IEEE + - * / only, so CPU and GPU agree bit for bit);   */
+/*   means / products sequential in ascending position; binomial CDFs (SciPy's              */
+/*   binom.cdf, :458,:478) by the float64 pmf recurrence; threshold comparisons in float64. */
+/* out_i32: {num_teps, winner_index, correct, frontier_comparisons, suc1, suc2, stop}       */
+/*   stop: 0 = ran all N_max-1 TEPs, 1 = promising-probability stop, 2 = success stop       */
+/* ------------------------------------------------------------------------------------ */
+static float det_expf(float x)
+{
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) return 0.0f;
+    float kf = floorf(x * 1.44269504f + 0.5f);
+    float r = (x - kf * 0.693359375f) - kf * -2.12194440e-4f;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    float e = (p * (r * r) + r) + 1.0f;
+    union { float f; int32_t i; } u;
+    u.i = ((int32_t)kf + 127) << 23;
+    return e * u.f;
+}
+
+static float det_sigmoidf(float z) { return 1.0f / (1.0f + det_expf(-z)); }
+
+/* cdf[b] = P[Binomial(64, p) <= b], b = 0..64, by the pmf recurrence in float64 */
+static void binom_cdf_table(double p, double *cdf)
+{
+    double q = 1.0 - p, t = q;
+    for (int s = 0; s < 6; ++s) t = t * t; /* q^64 */
+    double ratio = p / q, acc = t;
+    cdf[0] = acc;
+    for (int i = 0; i < 64; ++i) {
+        t = t * ((double)(64 - i) / (double)(i + 1)) * ratio;
+        acc = acc + t;
+        cdf[i + 1] = acc;
+    }
+}
+
+typedef struct { float sum; uint32_t seq; uint8_t pos[3]; uint8_t w; } pb_entry;
+
+int orc_pb_osd(const int32_t *G, const float *y, const uint8_t *label, int order, float snr_db, int32_t *out_i32,
+               float *out_metric, uint8_t *cw_orig)
+{
+    int32_t perm[128], Gp[64 * 128];
+    float yp[128];
+    osd_frame f;
+    if (orc_osd_front(G, 64, 128, y, perm, Gp, NULL, NULL)) return -1;
+    for (int p = 0; p < 128; ++p) yp[p] = y[perm[p]];
+    frame_prepare(&f, yp, Gp);
+    const float c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)snr_db / 10.0)));
+    float q[128];
+    for (int p = 0; p < 128; ++p) q[p] = det_sigmoidf(c4 * f.w[p]);
+    float acc = 0.0f, accw = 0.0f;
+    for (int p = 64; p < 128; ++p) { acc = acc + q[p]; accw = accw + f.w[p]; }
+    const float p1 = acc / 64.0f, lrb_mean = accw / 64.0f;          /* mean_lrb_prob :406-411, beta_acquire :401 */
+    acc = 0.0f;
+    for (int p = 0; p < 64; ++p) acc = acc + q[p];
+    const float pt = acc / 64.0f;                                   /* mean_mrb_prob :463-468 */
+    float spl = 1.0f;
+    for (int p = 0; p < 64; ++p) spl = spl * (1.0f - q[p]);         /* com_mrb_prob :35-41 */
+    double cdfA[65], cdfH[65], cdfT[65];
+    binom_cdf_table((double)p1, cdfA);
+    binom_cdf_table(0.5, cdfH);
+    binom_cdf_table((double)pt, cdfT);
+    const double niu = cdfT[order];                                 /* calculate_two_thresholds :485-500 */
+    int64_t nmax = 0;
+    for (int w = 0; w <= order; ++w) nmax += choose(64, w);
+    const double p_t_suc = 0.99 * niu, p_t_pro = 0.002 * sqrt((1.0 - niu) / (double)nmax);
+
+    pb_entry *fr = (pb_entry *)malloc(sizeof(pb_entry) * (size_t)(nmax + 2));
+    int nfr = 1;
+    uint32_t seq = 1;
+    fr[0].sum = f.w[63]; fr[0].seq = 0; fr[0].pos[0] = 63; fr[0].w = 1;   /* starting point k-1 :109-110 */
+    float best = frame_cost(&f, 0.0f, f.d0);
+    uint64_t bestD = f.d0, bestE = 0;
+    int bestidx = 0, stop = 0, ntep = (int)nmax, cmp = 0, suc1 = 0, suc2 = 0;
+    for (int64_t j = 0; j < nmax - 1 && nfr > 0; ++j) {
+        /* optimal_tep_sequence :366-397: first minimum of the reliability sums in list order */
+        int mi = 0;
+        for (int t = 1; t < nfr; ++t)
+            if (fr[t].sum < fr[mi].sum || (fr[t].sum == fr[mi].sum && fr[t].seq < fr[mi].seq)) mi = t;
+        cmp += nfr == 1 ? 1 : 2;
+        pb_entry e = fr[mi];
+        fr[mi] = fr[--nfr];                       /* order is carried by seq, so a swap-remove is fine */
+        const int last = e.pos[e.w - 1];
+        if (last < 63 && e.w < order) {           /* extended child: e U {k-1} */
+            pb_entry c = e; c.pos[c.w++] = 63; c.sum = e.sum + f.w[63]; c.seq = seq++; fr[nfr++] = c;
+        }
+        if (e.w > 1) {                            /* adjacent child: largest index moves down by one */
+            if (last - e.pos[e.w - 2] > 1) {
+                pb_entry c = e; c.pos[c.w - 1] = (uint8_t)(last - 1);
+                float s = 0.0f; for (int t = 0; t < c.w; ++t) s = t ? s + f.w[c.pos[t]] : f.w[c.pos[t]];
+                c.sum = s; c.seq = seq++; fr[nfr++] = c;
+            }
+        } else if (last - 1 > -1) {
+            pb_entry c = e; c.pos[0] = (uint8_t)(last - 1); c.sum = f.w[last - 1]; c.seq = seq++; fr[nfr++] = c;
+        }
+        /* acquire_prob_promising :448-461 */
+        const float rs = e.sum;
+        const float w1 = det_expf(c4 * rs) * spl, w2 = 1.0f - w1;
+        float bt = floorf((best - rs) / lrb_mean);
+        int beta = bt > 0.0f ? (bt < 64.0f ? (int)bt : 64) : 0;
+        float bs = 0.0f;
+        bs = bs + w1 * (float)cdfA[beta];
+        bs = bs + w2 * (float)cdfH[beta];
+        if ((double)bs < p_t_pro) { stop = 1; ntep = (int)j + 1; break; }
+        uint64_t D = f.d0, E = 0;
+        for (int t = 0; t < e.w; ++t) { D ^= f.P[e.pos[t]]; E |= 1ull << e.pos[t]; }
+        const float cost = frame_cost(&f, rs, D);
+        ++suc1;
+        if (cost < best) {
+            best = cost; bestD = D; bestE = E; bestidx = (int)j + 1;
+            /* acquire_p_e_suc :423-436 */
+            const float ratio = (1.0f - w1) / w1;
+            float prod = 1.0f;
+            for (int p = 0; p < 64; ++p) prod = prod * (((D >> p) & 1) ? 2.0f * q[64 + p] : 2.0f * (1.0f - q[64 + p]));
+            const float p_suc = 1.0f / (1.0f + ratio / prod);
+            ++suc2;
+            if ((double)p_suc > p_t_suc) { stop = 2; ntep = (int)j + 1; break; }
+        }
+    }
+    free(fr);
+    uint8_t cw[128];
+    codeword_to_original(&f, f.hm ^ bestE, bestD, perm, cw);
+    out_i32[0] = ntep; out_i32[1] = bestidx; out_i32[2] = label ? memcmp(cw, label, 128) == 0 : 0;
+    out_i32[3] = cmp; out_i32[4] = suc1; out_i32[5] = suc2; out_i32[6] = stop;
+    if (out_metric) *out_metric = best;
+    if (cw_orig) memcpy(cw_orig, cw, 128);
+    return 0;
+}
+
+int orc_pb_osd_batch(const int32_t *G, const float *y, const uint8_t *labels, int64_t F, int order, float snr_db,
+                     int32_t *out_i32 /*[F][7]*/, float *out_metric /*[F]*/, uint8_t *cw_orig /*[F][128]*/)
+{
+    int rc = 0;
+    for (int64_t i = 0; i < F && !rc; ++i)
+        rc = orc_pb_osd(G, y + i * 128, labels ? labels + i * 128 : NULL, order, snr_db, out_i32 + 7 * i,
+                        out_metric ? out_metric + i : NULL, cw_orig ? cw_orig + i * 128 : NULL);
+    return rc;
+}
+
+/* exported for the tests that pin det_expf / the CDF recurrence against libm / SciPy */
+float orc_det_expf(float x) { return det_expf(x); }
+void orc_binom_cdf64(double p, double *cdf65) { binom_cdf_table(p, cdf65); }

@@ -483,3 +483,92 @@ def fs_osd_frame(yp, labelp, Gp, order, beta=0.1, tau_e=6.5, tau_psc=30.0):
     fail_ref = None if labelp is None else bool(np.any(best_cw != np.asarray(labelp)))
     return dict(codeword_ref=best_cw, metric_ref=w_dmin, codeword_hit=hit_cw, metric_hit=hit_metric,
                 num_teps=num_teps, fail_ref=fail_ref)
+
+
+# --------------------------------------------------------------------------------------
+# PB-OSD:  PB_OSD/pb_testing.py:35-41, 100-149, 366-500
+# --------------------------------------------------------------------------------------
+
+
+def _sigmoid32(x):
+    return (F32(1) / (F32(1) + np.exp(-np.asarray(x, dtype=F32)))).astype(F32)
+
+
+def pb_osd_frame(yp, labelp, Gp, order, snr_db):
+    """One frame of ``pb_osd`` (pb_testing.py:100-149) in the primed domain, written with NumPy's
+    exp and SciPy's binom.cdf (what the reference calls, :458,:478) -- i.e. NOT with the
+    deterministic float routines of the C oracle; the two agree except for decisions that sit
+    within float rounding of a threshold.  Returns dict(codeword, metric, num_teps, best_index,
+    comparisons, stop, fail)."""
+    import scipy.stats as stats
+
+    yp = np.asarray(yp, dtype=F32)
+    k, n = Gp.shape
+    w = np.abs(yp)
+    hard = np.where(yp > 0, 0, 1).astype(np.int64)
+    c4 = F32(-4.0 * (1.0 / 10 ** (snr_db / 10)))                       # :50-52, used as -4*noise_variance
+    q = _sigmoid32(c4 * w)
+    p1 = F32(np.add.reduce(q[k:], dtype=F32) / F32(n - k))              # mean_lrb_prob :406-411
+    pt = F32(np.add.reduce(q[:k], dtype=F32) / F32(k))                  # mean_mrb_prob :463-468
+    lrb_mean = F32(np.add.reduce(w[k:], dtype=F32) / F32(n - k))        # beta_acquire :401
+    spl = F32(1)
+    for i in range(k):                                                  # com_mrb_prob :35-41
+        spl = F32(spl * (F32(1) - q[i]))
+    niu = float(stats.binom.cdf(order, k, float(pt)))                   # :478, :489
+    nmax = sum(math.comb(k, i) for i in range(order + 1))
+    p_t_suc, p_t_pro = 0.99 * niu, 0.002 * math.sqrt((1 - niu) / nmax)  # :490-498
+
+    def encode(support):
+        mrb = hard[:k].copy()
+        for p in support:
+            mrb[p] ^= 1
+        cw = mrb.dot(Gp) % 2
+        disc = (cw + hard) % 2
+        return cw, disc, _weighted_distance_k(disc, w, k)
+
+    def rsum(support):
+        acc = F32(0)
+        for p in sorted(support):
+            acc = F32(acc + w[p])
+        return acc
+
+    best_cw, _, w_dmin = encode(())                                     # :101-106
+    frontier = [(k - 1,)]                                               # :109-110
+    num_teps, best_index, comparisons, stop = nmax, 0, 0, 0
+    for j in range(nmax - 1):                                           # :120
+        sums = [rsum(s) for s in frontier]
+        mi = int(np.argmin(np.array(sums, dtype=F32)))                  # :370 first minimum
+        comparisons += 1 if len(frontier) == 1 else 2                   # :371-374
+        sel = frontier.pop(mi)
+        if sel[-1] < k - 1 and len(sel) < order:                        # :381-384
+            frontier.append(sel + (k - 1,))
+        if len(sel) > 1:                                                # :386-391
+            if sel[-1] - sel[-2] > 1:
+                frontier.append(sel[:-1] + (sel[-1] - 1,))
+        elif sel[-1] - 1 > -1:                                          # :392-396
+            frontier.append((sel[-1] - 1,))
+        rs = sums[mi]
+        w1 = F32(np.exp(F32(c4 * rs)) * spl)                            # tep_prob :441-445
+        w2 = F32(F32(1) - w1)
+        bt = np.floor(F32(F32(w_dmin - rs) / lrb_mean))                 # beta_acquire :399-405
+        beta = 0 if not bt > 0 else (64 if bt > 64 else int(bt))
+        bs = F32(0)
+        bs = F32(bs + w1 * F32(stats.binom.cdf(beta, n - k, float(p1))))
+        bs = F32(bs + w2 * F32(stats.binom.cdf(beta, n - k, 0.5)))
+        if float(bs) < p_t_pro:                                         # :129-132
+            stop, num_teps = 1, j + 1
+            break
+        cw, disc, wd = encode(sel)
+        if wd < w_dmin:                                                 # :138-149
+            best_cw, w_dmin, best_index = cw, wd, j + 1
+            ratio = F32(F32(F32(1) - w1) / w1)
+            prod = F32(1)
+            for i in range(k, n):
+                prod = F32(prod * (F32(2) * q[i] if disc[i] else F32(2) * (F32(1) - q[i])))
+            p_suc = F32(F32(1) / F32(F32(1) + F32(ratio / prod)))
+            if float(p_suc) > p_t_suc:
+                stop, num_teps = 2, j + 1
+                break
+    fail = None if labelp is None else bool(np.any(best_cw != np.asarray(labelp)))
+    return dict(codeword=best_cw, metric=w_dmin, num_teps=num_teps, best_index=best_index,
+                comparisons=comparisons, stop=stop, fail=fail)

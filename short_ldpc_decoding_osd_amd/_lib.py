@@ -28,7 +28,7 @@ OSD_CONVENTIONAL, OSD_FS, OSD_PB = 0, 1, 2
 class OsdParams(C.Structure):
     _fields_ = [("order", C.c_int32), ("algo", C.c_int32), ("snr_db", C.c_float), ("fs_beta", C.c_float),
                 ("fs_tau_e", C.c_float), ("fs_tau_psc", C.c_float), ("fs_reference_quirk", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("d_aux", C.c_void_p)]
 
 
 class LdpcError(RuntimeError):

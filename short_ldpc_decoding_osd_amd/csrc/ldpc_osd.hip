@@ -21,6 +21,8 @@
 //                      evaluates one TEP per round: parity word = d0 ^ P'[i] ^ P'[j] ..., metric
 //                      = flipped-MRB weights + 8 LUT terms in a FIXED order (the canonical order
 //                      the oracle uses, see oracle/np_oracle.py weighted_distance), first minimum.
+#include <math.h>
+
 #include "ldpc_internal.h"
 
 namespace ldpc {
@@ -472,6 +474,223 @@ __global__ __launch_bounds__(256) void osd_fs_kernel(const float *__restrict__ y
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// PB-OSD (pb_osd, PB_OSD/pb_testing.py:100-149): best-first TEP generation from a frontier
+// (optimal_tep_sequence :366-397) with two probabilistic stopping rules
+// (acquire_prob_promising :448-461, acquire_p_e_suc :423-436, thresholds :485-500).
+// The search is sequential per frame; a wavefront owns a frame, the lanes share the frontier
+// scan (arg-min on (reliability sum, insertion number) == "first minimum in list order") and
+// the per-position set-up, everything else is wave-uniform.  All probabilities follow the float
+// conventions of the oracle (oracle/ldpc_oracle.c orc_pb_osd): float32 with det_expf (IEEE
+// + - * / only, so host and device agree bit for bit), float64 binomial-CDF recurrences,
+// threshold comparisons in float64.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float det_expf(float x)
+{
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) return 0.0f;
+    const float kf = __builtin_floorf(x * 1.44269504f + 0.5f);
+    const float r = (x - kf * 0.693359375f) - kf * -2.12194440e-4f;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    const float e = (p * (r * r) + r) + 1.0f;
+    return e * __int_as_float(((int)kf + 127) << 23);
+}
+
+struct PbEntry {
+    float sum;          // reliability sum of the flipped MRB positions (ascending, sequential)
+    unsigned seq;       // insertion number = position in the reference's growing list
+    unsigned pos;       // pos0 | pos1 << 8 | pos2 << 16 | weight << 24  (ascending positions)
+};
+constexpr int kPbLdsEntries = 384;
+
+struct __attribute__((aligned(16))) PbLds {
+    double cdfA[65];            // P[Bin(64, p1) <= b]
+    float q[128];               // sigmoid(c4 |y'_p|)
+    PbEntry fr[kPbLdsEntries];  // head of the frontier; the rest spills to global memory
+};
+
+struct PbParams {
+    int order, nmax;
+    float c4;
+};
+
+__device__ __forceinline__ PbEntry fr_get(const PbLds &B, const PbEntry *spill, int i)
+{
+    return i < kPbLdsEntries ? B.fr[i] : spill[i - kPbLdsEntries];
+}
+__device__ __forceinline__ void fr_put(PbLds &B, PbEntry *spill, int i, PbEntry e)
+{
+    if (i < kPbLdsEntries) B.fr[i] = e; else spill[i - kPbLdsEntries] = e;
+}
+
+__global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                     const int *__restrict__ count, long long F,
+                                                     const unsigned char *__restrict__ perm_in,
+                                                     const u64 *__restrict__ parity_in, PbParams P,
+                                                     const double *__restrict__ cdf_half /*[65]*/,
+                                                     const double *__restrict__ coef /*[64] (64-i)/(i+1)*/,
+                                                     PbEntry *__restrict__ spill_all, long long spill_stride,
+                                                     u64 *__restrict__ cw_out, float *__restrict__ metric_out,
+                                                     int *__restrict__ best_out, int *__restrict__ ntep_out,
+                                                     int *__restrict__ aux_out /*[F][4] or null*/)
+{
+    __shared__ SearchLds lds[4];
+    __shared__ PbLds pbl[4];
+    const int lane = threadIdx.x & 63;
+    SearchLds &L = lds[threadIdx.x >> 6];
+    PbLds &B = pbl[threadIdx.x >> 6];
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    PbEntry *spill = spill_all + wave * spill_stride;
+
+    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+        const long long src = index ? index[f] : f;
+        const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+        B.q[lane] = 1.0f / (1.0f + det_expf(-(P.c4 * L.w[lane])));
+        B.q[lane + 64] = 1.0f / (1.0f + det_expf(-(P.c4 * L.w[lane + 64])));
+        wave_fence();
+        // sequential (ascending position) means / product, as the oracle defines them
+        float a1 = 0.0f, aw = 0.0f, at = 0.0f, spl = 1.0f;
+        for (int p = 0; p < 64; ++p) {
+            a1 = a1 + B.q[64 + p];
+            aw = aw + L.w[64 + p];
+            at = at + B.q[p];
+            spl = spl * (1.0f - B.q[p]);
+        }
+        const float p1 = a1 / 64.0f, lrb_mean = aw / 64.0f, pt = at / 64.0f;
+        // binomial CDF tables by the pmf recurrence (float64): full table for p1, up to `order` for pt
+        double niu;
+        {
+            double q = 1.0 - (double)p1, t = q;
+            for (int s = 0; s < 6; ++s) t = t * t;
+            const double ratio = (double)p1 / q;
+            double acc = t;
+            if (lane == 0) B.cdfA[0] = acc;
+            for (int i = 0; i < 64; ++i) {
+                t = t * coef[i] * ratio;
+                acc = acc + t;
+                if (lane == 0) B.cdfA[i + 1] = acc;
+            }
+            q = 1.0 - (double)pt; t = q;
+            for (int s = 0; s < 6; ++s) t = t * t;
+            const double ratio2 = (double)pt / q;
+            acc = t;
+            for (int i = 0; i < P.order; ++i) { t = t * coef[i] * ratio2; acc = acc + t; }
+            niu = acc;
+        }
+        const double p_t_suc = 0.99 * niu, p_t_pro = 0.002 * __builtin_sqrt((1.0 - niu) / (double)P.nmax);
+        if (lane == 0) { PbEntry e0; e0.sum = L.w[63]; e0.seq = 0; e0.pos = 63u | (1u << 24); B.fr[0] = e0; }
+        wave_fence();
+        int nfr = 1, ntep = P.nmax, bestidx = 0, stop = 0, cmp = 0, suc1 = 0, suc2 = 0;
+        unsigned seq = 1;
+        float best = tep_cost(L, 0.0f, S.d0);
+        u64 bestD = S.d0, bestE = 0;
+        for (int j = 0; j < P.nmax - 1 && nfr > 0; ++j) {
+            // first minimum of the frontier in list order
+            float ms = __builtin_inff();
+            int mi = 0x7FFFFFFF;
+            u64 mseq = ~0ull, dummy = 0;
+            for (int t = lane; t < nfr; t += 64) {
+                const PbEntry c = fr_get(B, spill, t);
+                if (c.sum < ms || (c.sum == ms && c.seq < (unsigned)mseq)) { ms = c.sum; mi = t; mseq = c.seq; }
+            }
+            {   // arg-min on (sum, seq); carry the slot index along
+                int key = (int)(unsigned)mseq;
+                u64 slot = (u64)(unsigned)mi;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float os = __shfl(ms, lane ^ off, 64);
+                    const int ok = __shfl(key, lane ^ off, 64);
+                    const u64 osl = shfl64(slot, lane ^ off);
+                    if (os < ms || (os == ms && (unsigned)ok < (unsigned)key)) { ms = os; key = ok; slot = osl; }
+                }
+                mi = (int)slot;
+                (void)dummy;
+            }
+            cmp += nfr == 1 ? 1 : 2;
+            const PbEntry e = fr_get(B, spill, mi);
+            const int ew = (int)(e.pos >> 24);
+            const int p0 = e.pos & 0xFF, pA = (e.pos >> 8) & 0xFF, pB = (e.pos >> 16) & 0xFF;
+            const int last = ew == 1 ? p0 : (ew == 2 ? pA : pB);
+            const int prev = ew == 2 ? p0 : pA;     // second largest (ew > 1)
+            wave_fence();
+            if (lane == 0) {
+                --nfr;
+                if (mi != nfr) fr_put(B, spill, mi, fr_get(B, spill, nfr));
+                if (last < 63 && ew < P.order) {            // extended child: e U {63}
+                    PbEntry c = e;
+                    c.pos = (e.pos & 0x00FFFFFFu) | (63u << (8 * ew)) | ((unsigned)(ew + 1) << 24);
+                    c.sum = e.sum + L.w[63];
+                    c.seq = seq++;
+                    fr_put(B, spill, nfr++, c);
+                }
+                if (ew > 1) {                               // adjacent child: largest index moves down by one
+                    if (last - prev > 1) {
+                        PbEntry c = e;
+                        c.pos = (e.pos & ~(0xFFu << (8 * (ew - 1)))) | ((unsigned)(last - 1) << (8 * (ew - 1)));
+                        const int q0 = c.pos & 0xFF, q1 = (c.pos >> 8) & 0xFF, q2 = (c.pos >> 16) & 0xFF;
+                        float sacc = L.w[q0] + L.w[q1];
+                        if (ew > 2) sacc = sacc + L.w[q2];
+                        c.sum = sacc;
+                        c.seq = seq++;
+                        fr_put(B, spill, nfr++, c);
+                    }
+                } else if (last - 1 > -1) {
+                    PbEntry c = e;
+                    c.pos = (unsigned)(last - 1) | (1u << 24);
+                    c.sum = L.w[last - 1];
+                    c.seq = seq++;
+                    fr_put(B, spill, nfr++, c);
+                }
+            }
+            nfr = __builtin_amdgcn_readfirstlane(nfr);
+            seq = __builtin_amdgcn_readfirstlane(seq);
+            __threadfence_block();
+            wave_fence();
+            // promising-probability rule
+            const float rs = e.sum;
+            const float w1 = det_expf(P.c4 * rs) * spl, w2 = 1.0f - w1;
+            const float bt = __builtin_floorf((best - rs) / lrb_mean);
+            const int beta = bt > 0.0f ? (bt < 64.0f ? (int)bt : 64) : 0;
+            float bs = 0.0f;
+            bs = bs + w1 * (float)B.cdfA[beta];
+            bs = bs + w2 * (float)cdf_half[beta];
+            if ((double)bs < p_t_pro) { stop = 1; ntep = j + 1; break; }
+            u64 D = S.d0 ^ L.P[p0], E = 1ull << p0;
+            if (ew > 1) { D ^= L.P[pA]; E |= 1ull << pA; }
+            if (ew > 2) { D ^= L.P[pB]; E |= 1ull << pB; }
+            const float cost = tep_cost(L, rs, D);
+            ++suc1;
+            if (cost < best) {
+                best = cost; bestD = D; bestE = E; bestidx = j + 1;
+                const float ratio = (1.0f - w1) / w1;
+                float prod = 1.0f;
+                for (int p = 0; p < 64; ++p) {
+                    const float qp = B.q[64 + p];
+                    prod = prod * (((D >> p) & 1) ? 2.0f * qp : 2.0f * (1.0f - qp));
+                }
+                const float p_suc = 1.0f / (1.0f + ratio / prod);
+                ++suc2;
+                if ((double)p_suc > p_t_suc) { stop = 2; ntep = j + 1; break; }
+            }
+        }
+        search_finish(L, S, bestE, bestD, f, lane, cw_out);
+        if (lane == 0) {
+            if (metric_out) metric_out[f] = best;
+            if (best_out) best_out[f] = bestidx;
+            if (ntep_out) ntep_out[f] = ntep;
+            if (aux_out) { aux_out[f * 4] = cmp; aux_out[f * 4 + 1] = suc1; aux_out[f * 4 + 2] = suc2; aux_out[f * 4 + 3] = stop; }
+        }
+        wave_fence();
+    }
+}
+
 __global__ __launch_bounds__(256) void osd_counts_kernel(const u64 *__restrict__ cw, const u64 *__restrict__ label,
                                                          const int *__restrict__ index, const int *__restrict__ count,
                                                          const int *__restrict__ ntep, long long F,
@@ -504,6 +723,10 @@ __global__ __launch_bounds__(256) void osd_counts_kernel(const u64 *__restrict__
 struct OsdState {
     int64_t ntep[4] = {0, 0, 0, 0};
     uchar4 *d_tep_fs = nullptr;       // FS visit order, weight classes 1..3 back to back
+    double *d_cdf_half = nullptr;     // PB-OSD: P[Bin(64, 1/2) <= b], b = 0..64
+    double *d_coef = nullptr;         // PB-OSD: (64-i)/(i+1)
+    void *d_pb_spill = nullptr;       // PB-OSD frontier overflow [waves][stride]
+    int64_t pb_spill_stride = 0;
     int fs_off[4] = {0, 0, 0, 0}, fs_cnt[4] = {0, 0, 0, 0};
     unsigned char *d_perm = nullptr;  // workspace [cap][128]
     u64 *d_parity = nullptr;          // workspace [cap][64]
@@ -554,6 +777,19 @@ int osd_ctx_init(ldpc_ctx *ctx)
     }
     LDPC_HIP(hipMalloc((void **)&st->d_tep_fs, fs.size()));
     LDPC_HIP(hipMemcpy(st->d_tep_fs, fs.data(), fs.size(), hipMemcpyHostToDevice));
+    // PB-OSD constants, same float64 recurrence as the kernel / oracle
+    {
+        double coef[64], cdf[65], t = 0.5;
+        for (int i = 0; i < 64; ++i) coef[i] = (double)(64 - i) / (double)(i + 1);
+        for (int q = 0; q < 6; ++q) t = t * t;
+        double acc = t;
+        cdf[0] = acc;
+        for (int i = 0; i < 64; ++i) { t = t * coef[i] * (0.5 / 0.5); acc = acc + t; cdf[i + 1] = acc; }
+        LDPC_HIP(hipMalloc((void **)&st->d_cdf_half, sizeof(cdf)));
+        LDPC_HIP(hipMemcpy(st->d_cdf_half, cdf, sizeof(cdf), hipMemcpyHostToDevice));
+        LDPC_HIP(hipMalloc((void **)&st->d_coef, sizeof(coef)));
+        LDPC_HIP(hipMemcpy(st->d_coef, coef, sizeof(coef), hipMemcpyHostToDevice));
+    }
     ctx->osd_ok = true;
     return LDPC_OK;
 }
@@ -566,6 +802,9 @@ void osd_ctx_release(ldpc_ctx *ctx)
         (void)hipFree(st->d_perm);
         (void)hipFree(st->d_parity);
         (void)hipFree(st->d_tep_fs);
+        (void)hipFree(st->d_cdf_half);
+        (void)hipFree(st->d_coef);
+        (void)hipFree(st->d_pb_spill);
         delete st;
     }
     ctx->osd_state = nullptr;
@@ -639,8 +878,9 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
     if (!ctx || !p || F < 0 || (F > 0 && (!d_y || !d_cw))) return fail(LDPC_E_ARG, "ldpc_osd_decode: bad arguments");
     if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
     if (p->order < 0 || p->order > 3) return fail(LDPC_E_ARG, "ldpc_osd_decode: order %d outside 0..3", p->order);
-    if (p->algo != LDPC_OSD_CONVENTIONAL && p->algo != LDPC_OSD_FS)
-        return fail(LDPC_E_UNSUPPORTED, "ldpc_osd_decode: search algorithm %d is not built yet (conventional = 0, FS = 1 are)", p->algo);
+    if (p->algo != LDPC_OSD_CONVENTIONAL && p->algo != LDPC_OSD_FS && p->algo != LDPC_OSD_PB)
+        return fail(LDPC_E_ARG, "ldpc_osd_decode: unknown search algorithm %d", p->algo);
+    if (p->algo == LDPC_OSD_PB && p->order < 1) return fail(LDPC_E_ARG, "ldpc_osd_decode: PB-OSD needs order >= 1");
     if (F == 0) return LDPC_OK;
     OsdState *st = state(ctx);
     if (F > st->cap) {
@@ -653,7 +893,28 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(osd_front_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
                        reinterpret_cast<const u64 *>(ctx->d_Gcols), st->d_perm, st->d_parity, (int *)nullptr);
-    if (p->algo == LDPC_OSD_FS) {
+    if (p->algo == LDPC_OSD_PB) {
+        const int64_t nmax = st->ntep[p->order];
+        const unsigned blocks = osd_grid(F) < 512 ? osd_grid(F) : 512;       // bounded: each wave owns a spill area
+        const int64_t stride = nmax > kPbLdsEntries ? nmax - kPbLdsEntries + 2 : 2;
+        if (stride > st->pb_spill_stride) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                return fail(LDPC_E_NOMEM, "ldpc_osd_decode: PB-OSD frontier workspace must be sized before capturing (run one call first)");
+            (void)hipFree(st->d_pb_spill);
+            st->d_pb_spill = nullptr; st->pb_spill_stride = 0;
+            if (hipMalloc(&st->d_pb_spill, sizeof(PbEntry) * (size_t)stride * 512 * 4) != hipSuccess)
+                return fail(LDPC_E_NOMEM, "ldpc_osd_decode: PB-OSD frontier workspace (%lld entries per wave) could not be allocated", (long long)stride);
+            st->pb_spill_stride = stride;
+        }
+        PbParams pp;
+        pp.order = p->order; pp.nmax = (int)nmax;
+        pp.c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)p->snr_db / 10.0)));    // -4 * noise_variance, pb_testing.py:50-52
+        hipLaunchKernelGGL(osd_pb_kernel, dim3(blocks), dim3(256), 0, s, d_y, d_index, d_count, (long long)F, st->d_perm,
+                           st->d_parity, pp, st->d_cdf_half, st->d_coef, reinterpret_cast<PbEntry *>(st->d_pb_spill),
+                           (long long)st->pb_spill_stride, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep,
+                           reinterpret_cast<int *>(p->d_aux));
+    } else if (p->algo == LDPC_OSD_FS) {
         FsParams fp;
         fp.order = p->order; fp.quirk = p->fs_reference_quirk != 0;
         fp.beta_term = (float)((double)p->fs_beta * (double)(kOsdN - kOsdK));   // fs_testing.py:138

@@ -149,3 +149,34 @@ def test_fs_osd_c_vs_numpy(np_code):
                 ch = np.empty(128, dtype=np.int64)
                 ch[perm] = o["codeword_hit"]
                 assert np.array_equal(ch, res["codeword_hit"][j]) and o["metric_hit"] == res["metric_hit"][j]
+
+
+def test_pb_deterministic_math_is_accurate():
+    """det_expf / the CDF recurrence used by the C oracle (and the kernel) against libm / SciPy."""
+    import scipy.stats as st
+    x = np.linspace(-30, 10, 4001).astype(np.float32)
+    ref = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(c_oracle.det_expf(x) - ref) / ref) < 2e-7
+    for p in (0.5, 0.2, 0.03, 1e-4):
+        assert np.allclose(c_oracle.binom_cdf64(p), st.binom.cdf(np.arange(65), 64, p), rtol=1e-12, atol=1e-15)
+
+
+def test_pb_osd_c_vs_numpy(np_code):
+    """PB-OSD: the deterministic C restatement against the literal NumPy/SciPy one
+    (pb_testing.py:100-149).  Decisions may differ only within float rounding of a threshold."""
+    rng = np.random.default_rng(0)
+    y, cw = np_oracle.make_frames(np_code.G, 2.5, 400, rng)
+    soft = c_oracle.nms(np_code.H, y, 10, 0.669435)
+    _, fail, _ = c_oracle.evaluate(np_code.H, soft, cw)
+    idx = np.flatnonzero(fail)[:25]
+    res = c_oracle.pb_osd(np_code.G, y[idx], cw[idx], 2, 2.5)
+    same = 0
+    for j, i in enumerate(idx):
+        yp, lp, Gp, perm, _ = np_oracle.swapped_info(y[i], cw[i], np_code.G)
+        o = np_oracle.pb_osd_frame(yp, lp, Gp, 2, 2.5)
+        cwo = np.empty(128, dtype=np.int64)
+        cwo[perm] = o["codeword"]
+        same += (o["num_teps"] == res["num_teps"][j] and o["stop"] == res["stop"][j]
+                 and o["comparisons"] == res["comparisons"][j] and o["best_index"] == res["best_index"][j]
+                 and np.array_equal(cwo, res["codeword"][j]) and o["fail"] == (not res["correct"][j]))
+    assert same >= len(idx) - 1
