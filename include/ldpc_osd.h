@@ -91,6 +91,10 @@ int64_t ldpc_tep_table(int32_t k, int32_t order, uint8_t *supports, int64_t *bou
  * supports: [C(k,weight)][3] uint8 ascending positions, 0xFF padded (NULL = only the count).   */
 int64_t ldpc_tep_table_fs(int32_t k, int32_t weight, uint8_t *supports);
 
+/* CRC-32C of a host buffer: the record checksum of the TFRecord files the reference's stages
+ * exchange (Ldpc_128_testing/data_generating.py:16-26, read_TFdata.py:18-29).                   */
+uint32_t ldpc_crc32c(const void *data, uint64_t len);
+
 /* ---------------------------------------------------------------------------------------
  * Device context: uploads the packed H/G, Tanner-graph tables and TEP tables of one code
  * to one GPU.  Immutable after creation; one ctx per device; decode calls on distinct
@@ -189,6 +193,14 @@ typedef struct ldpc_osd_params {
 int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
                     const ldpc_osd_params *params, uint64_t *d_cw, float *d_metric, int32_t *d_best,
                     int32_t *d_ntep, void *stream);
+
+/* The search alone, on front-end results supplied by the caller (ldpc_osd_front, or any
+ * (perm, P') pair: with perm = identity and d_y already in the primed order this is exactly
+ * convention_osd_main / the fs_osd / pb_osd inner loops applied to (updated_inputs, reduced_G)). */
+int ldpc_osd_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                    const uint8_t *d_perm /*[F][128]*/, const uint64_t *d_parity /*[F][64]*/,
+                    const ldpc_osd_params *params, uint64_t *d_cw, float *d_metric, int32_t *d_best, int32_t *d_ntep,
+                    void *stream);
 
 /* OSD statistics against labels: d_counts[3] += {frames, frames_wrong, teps_total}.
  * (the success test of convention_osd.py:65-66 / pb_testing.py:158 / fs_testing.py:162)   */

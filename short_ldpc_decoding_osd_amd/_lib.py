@@ -15,10 +15,10 @@ LIB_PATH = os.path.join(_HERE, "libldpcosd.so")
 SYMBOLS = (
     "ldpc_last_error", "ldpc_abi_version",
     "ldpc_code_from_alist", "ldpc_code_from_dense", "ldpc_code_destroy", "ldpc_code_dims",
-    "ldpc_code_get_H", "ldpc_code_get_G", "ldpc_gf2elim_host", "ldpc_tep_table", "ldpc_tep_table_fs",
+    "ldpc_code_get_H", "ldpc_code_get_G", "ldpc_gf2elim_host", "ldpc_tep_table", "ldpc_tep_table_fs", "ldpc_crc32c",
     "ldpc_ctx_create", "ldpc_ctx_destroy", "ldpc_ctx_nms_kernel",
     "ldpc_nms_decode", "ldpc_eval_counts", "ldpc_compact", "ldpc_pack_bits", "ldpc_unpack_bits",
-    "ldpc_osd_reserve", "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_decode", "ldpc_osd_counts",
+    "ldpc_osd_reserve", "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_search", "ldpc_osd_decode", "ldpc_osd_counts",
 )
 
 NMS_AUTO, NMS_GENERIC, NMS_QC16 = 0, 1, 2
@@ -62,6 +62,7 @@ def load():
         "ldpc_gf2elim_host": (C.c_int, [pi32, i32, i32, pi32, pi32, pi32]),
         "ldpc_tep_table": (i64, [i32, i32, C.POINTER(C.c_uint8), pi64]),
         "ldpc_tep_table_fs": (i64, [i32, i32, C.POINTER(C.c_uint8)]),
+        "ldpc_crc32c": (C.c_uint32, [vp, C.c_uint64]),
         "ldpc_ctx_create": (C.c_int, [vp, i32, C.POINTER(vp)]),
         "ldpc_ctx_destroy": (None, [vp]),
         "ldpc_ctx_nms_kernel": (C.c_int, [vp]),
@@ -74,6 +75,7 @@ def load():
         "ldpc_osd_reserve": (C.c_int, [vp, i64]),
         "ldpc_osd_ge": (C.c_int, [vp, vp, i64, vp, vp, vp, vp]),
         "ldpc_osd_front": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp]),
+        "ldpc_osd_search": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, C.POINTER(OsdParams), vp, vp, vp, vp, vp]),
         "ldpc_osd_decode": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(OsdParams), vp, vp, vp, vp, vp]),
         "ldpc_osd_counts": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, vp]),
     }

@@ -331,6 +331,25 @@ int64_t ldpc_tep_table(int32_t k, int32_t order, uint8_t *supports, int64_t *bou
     return tep_table(k, order, supports, boundaries);
 }
 
+// CRC-32C (Castagnoli), the checksum of the TFRecord framing (tensorflow/core/lib/hash/crc32c)
+uint32_t ldpc_crc32c(const void *data, uint64_t len)
+{
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int b = 0; b < 8; ++b) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+            table[i] = c;
+        }
+        ready = true;
+    }
+    const uint8_t *p = static_cast<const uint8_t *>(data);
+    uint32_t c = 0xFFFFFFFFu;
+    for (uint64_t i = 0; i < len; ++i) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
 int64_t ldpc_tep_table_fs(int32_t k, int32_t weight, uint8_t *supports) { return tep_table_fs(k, weight, supports); }
 
 }  // extern "C"

@@ -871,28 +871,22 @@ int ldpc_osd_front(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, cons
     return LDPC_OK;
 }
 
-int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
-                    const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric, int32_t *d_best, int32_t *d_ntep,
-                    void *stream)
+static int check_params(ldpc_ctx *ctx, const ldpc_osd_params *p, const char *who)
 {
-    if (!ctx || !p || F < 0 || (F > 0 && (!d_y || !d_cw))) return fail(LDPC_E_ARG, "ldpc_osd_decode: bad arguments");
     if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
-    if (p->order < 0 || p->order > 3) return fail(LDPC_E_ARG, "ldpc_osd_decode: order %d outside 0..3", p->order);
+    if (p->order < 0 || p->order > 3) return fail(LDPC_E_ARG, "%s: order %d outside 0..3", who, p->order);
     if (p->algo != LDPC_OSD_CONVENTIONAL && p->algo != LDPC_OSD_FS && p->algo != LDPC_OSD_PB)
-        return fail(LDPC_E_ARG, "ldpc_osd_decode: unknown search algorithm %d", p->algo);
-    if (p->algo == LDPC_OSD_PB && p->order < 1) return fail(LDPC_E_ARG, "ldpc_osd_decode: PB-OSD needs order >= 1");
-    if (F == 0) return LDPC_OK;
+        return fail(LDPC_E_ARG, "%s: unknown search algorithm %d", who, p->algo);
+    if (p->algo == LDPC_OSD_PB && p->order < 1) return fail(LDPC_E_ARG, "%s: PB-OSD needs order >= 1", who);
+    return LDPC_OK;
+}
+
+// launches the search kernel selected by p->algo on front-end results (d_perm, d_parity)
+static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                         const unsigned char *d_perm, const u64 *d_parity, const ldpc_osd_params *p, uint64_t *d_cw,
+                         float *d_metric, int32_t *d_best, int32_t *d_ntep, hipStream_t s)
+{
     OsdState *st = state(ctx);
-    if (F > st->cap) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-            return fail(LDPC_E_NOMEM, "ldpc_osd_decode: workspace holds %lld frames, %lld needed; call ldpc_osd_reserve before capturing", (long long)st->cap, (long long)F);
-        int rc = reserve(ctx, F);
-        if (rc) return rc;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(osd_front_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
-                       reinterpret_cast<const u64 *>(ctx->d_Gcols), st->d_perm, st->d_parity, (int *)nullptr);
     if (p->algo == LDPC_OSD_PB) {
         const int64_t nmax = st->ntep[p->order];
         const unsigned blocks = osd_grid(F) < 512 ? osd_grid(F) : 512;       // bounded: each wave owns a spill area
@@ -910,8 +904,8 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
         PbParams pp;
         pp.order = p->order; pp.nmax = (int)nmax;
         pp.c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)p->snr_db / 10.0)));    // -4 * noise_variance, pb_testing.py:50-52
-        hipLaunchKernelGGL(osd_pb_kernel, dim3(blocks), dim3(256), 0, s, d_y, d_index, d_count, (long long)F, st->d_perm,
-                           st->d_parity, pp, st->d_cdf_half, st->d_coef, reinterpret_cast<PbEntry *>(st->d_pb_spill),
+        hipLaunchKernelGGL(osd_pb_kernel, dim3(blocks), dim3(256), 0, s, d_y, d_index, d_count, (long long)F, d_perm,
+                           d_parity, pp, st->d_cdf_half, st->d_coef, reinterpret_cast<PbEntry *>(st->d_pb_spill),
                            (long long)st->pb_spill_stride, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep,
                            reinterpret_cast<int *>(p->d_aux));
     } else if (p->algo == LDPC_OSD_FS) {
@@ -921,15 +915,50 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
         fp.tau_e = p->fs_tau_e; fp.tau_psc = p->fs_tau_psc;
         for (int w = 0; w < 4; ++w) { fp.cls_off[w] = st->fs_off[w]; fp.cls_cnt[w] = st->fs_cnt[w]; }
         hipLaunchKernelGGL(osd_fs_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
-                           st->d_perm, st->d_parity, st->d_tep_fs, fp, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
+                           d_perm, d_parity, st->d_tep_fs, fp, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
                            d_ntep);
     } else {
         hipLaunchKernelGGL(osd_search_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
-                           st->d_perm, st->d_parity, reinterpret_cast<const uchar4 *>(ctx->d_tep), (int)st->ntep[p->order],
+                           d_perm, d_parity, reinterpret_cast<const uchar4 *>(ctx->d_tep), (int)st->ntep[p->order],
                            reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
     }
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;
+}
+
+int ldpc_osd_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                    const uint8_t *d_perm, const uint64_t *d_parity, const ldpc_osd_params *p, uint64_t *d_cw,
+                    float *d_metric, int32_t *d_best, int32_t *d_ntep, void *stream)
+{
+    if (!ctx || !p || F < 0 || (F > 0 && (!d_y || !d_cw || !d_perm || !d_parity)))
+        return fail(LDPC_E_ARG, "ldpc_osd_search: bad arguments");
+    int rc = check_params(ctx, p, "ldpc_osd_search");
+    if (rc) return rc;
+    if (F == 0) return LDPC_OK;
+    return launch_search(ctx, d_y, d_index, d_count, F, d_perm, reinterpret_cast<const u64 *>(d_parity), p, d_cw, d_metric,
+                         d_best, d_ntep, (hipStream_t)stream);
+}
+
+int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                    const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric, int32_t *d_best, int32_t *d_ntep,
+                    void *stream)
+{
+    if (!ctx || !p || F < 0 || (F > 0 && (!d_y || !d_cw))) return fail(LDPC_E_ARG, "ldpc_osd_decode: bad arguments");
+    int rc = check_params(ctx, p, "ldpc_osd_decode");
+    if (rc) return rc;
+    if (F == 0) return LDPC_OK;
+    OsdState *st = state(ctx);
+    if (F > st->cap) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(LDPC_E_NOMEM, "ldpc_osd_decode: workspace holds %lld frames, %lld needed; call ldpc_osd_reserve before capturing", (long long)st->cap, (long long)F);
+        rc = reserve(ctx, F);
+        if (rc) return rc;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(osd_front_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
+                       reinterpret_cast<const u64 *>(ctx->d_Gcols), st->d_perm, st->d_parity, (int *)nullptr);
+    return launch_search(ctx, d_y, d_index, d_count, F, st->d_perm, st->d_parity, p, d_cw, d_metric, d_best, d_ntep, s);
 }
 
 int ldpc_osd_counts(ldpc_ctx *ctx, const uint64_t *d_cw, const uint64_t *d_label_bits, const int32_t *d_index,

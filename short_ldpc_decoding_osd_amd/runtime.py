@@ -183,6 +183,22 @@ class Decoder:
                    "ldpc_osd_decode")
         return out
 
+    def osd_search(self, y, perm, parity, params, index=None, count=None, F=None, out=None):
+        """Search only, on caller-supplied front-end results (perm [F,128] u8, parity [F,64] int64)."""
+        self._chk(y, torch.float32, (self.n,), "y")
+        self._chk(perm, torch.uint8, (128,), "perm")
+        self._chk(parity, torch.int64, (64,), "parity")
+        F = perm.shape[0] if F is None else F
+        out = dict(out or {})
+        for name, shape, dt in (("cw", (F, 2), torch.int64), ("metric", (F,), torch.float32),
+                                ("best", (F,), torch.int32), ("ntep", (F,), torch.int32)):
+            if out.get(name) is None:
+                out[name] = self.empty(shape, dt)
+        _lib.check(self.L.ldpc_osd_search(self._ctx, _ptr(y), _ptr(index), _ptr(count), F, _ptr(perm), _ptr(parity),
+                                          C.byref(params), _ptr(out["cw"]), _ptr(out["metric"]), _ptr(out["best"]),
+                                          _ptr(out["ntep"]), self._stream()), "ldpc_osd_search")
+        return out
+
     def osd_counts(self, cw, label_bits, index=None, count=None, ntep=None, counts=None, F=None):
         """counts[3] += {frames, frames_wrong, teps_total}; labels are looked up through index."""
         F = cw.shape[0] if F is None else F
