@@ -176,7 +176,7 @@ typedef struct ldpc_osd_params {
     float fs_tau_e;      /* FS-OSD floor(d_min-1)/2 as the reference evaluates it (6.5)    */
     float fs_tau_psc;    /* FS-OSD tau_psc, FS_OSD/globalmap.py:50 (30)                    */
     int32_t fs_reference_quirk; /* 1: keep optimal_codeword un-updated on a tau_e hit (fs_testing.py:145) */
-    int32_t reserved;
+    int32_t reserved;    /* 0; 1 = force the table-driven scan for order 2 (cross-check of the register-resident kernel) */
     void *d_aux;         /* optional DEVICE [F][4] i32, PB-OSD statistics per frame: {frontier comparisons
                             (memory_sum, pb_testing.py:122), suc counter 1 (:138), suc counter 2 (:144),
                             stop reason 0 = none / 1 = promising rule (:129) / 2 = success rule (:145)} */

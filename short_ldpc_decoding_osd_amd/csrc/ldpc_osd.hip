@@ -390,6 +390,81 @@ __global__ __launch_bounds__(256) void osd_search_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// Order-2 conventional search, register-resident: same result as osd_search_kernel with the
+// 2081-entry table, without per-TEP reads of P' / |y'| / the table.  Lane l keeps P'[l], P'[63-l],
+// |y'_l|, |y'_{63-l}|; order 1 = one TEP per lane; order 2 = 32 rounds over a triangular pairing
+//   lanes l > r : pair (r, l)          lanes l <= r : pair (62 - r, 63 - l)      (r = 0..31)
+// (63 - r) + (r + 1) = 64 pairs per round, 2016 in all; the pivot rows of a round arrive by
+// v_readlane.  "First minimum in table order" is kept by ranking the TEPs with the closed form of
+// the reference's ordering (weight class, then descending index sum, then ascending first index;
+// convention_osd.py:19-24): rank({}) = 0, rank({p}) = 64 - p, rank({i<j}) = 65 + base[i+j] +
+// i - max(0, i+j-63), base[s] = number of pairs with a larger sum (uploaded table).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int tep2_rank(int bi, int bj, const int *__restrict__ base2)
+{
+    if (bj < 0) return 0;
+    if (bi < 0) return 64 - bj;
+    const int s = bi + bj;
+    return 65 + base2[s] + bi - (s > 63 ? s - 63 : 0);
+}
+
+__global__ __launch_bounds__(256) void osd_search2_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                          const int *__restrict__ count, long long F,
+                                                          const unsigned char *__restrict__ perm_in,
+                                                          const u64 *__restrict__ parity_in,
+                                                          const int *__restrict__ base2,
+                                                          u64 *__restrict__ cw_out, float *__restrict__ metric_out,
+                                                          int *__restrict__ best_out, int *__restrict__ ntep_out)
+{
+    __shared__ SearchLds lds[4];
+    const int lane = threadIdx.x & 63;
+    SearchLds &L = lds[threadIdx.x >> 6];
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+
+    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+        const long long src = index ? index[f] : f;
+        const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+        const u64 Pl = L.P[lane], Pm = L.P[63 - lane];
+        const float wl = L.w[lane], wm = L.w[63 - lane];
+        // order 0 (rank 0, identical in every lane), then order 1: lane l owns TEP {l}
+        float best = tep_cost(L, 0.0f, S.d0);
+        int bi = -1, bj = -1;
+        u64 bestD = S.d0;
+        {
+            const u64 D = S.d0 ^ Pl;
+            const float c = tep_cost(L, wl, D);
+            if (c < best) { best = c; bj = lane; bestD = D; }      // a tie keeps the lower rank (order 0)
+        }
+        for (int r = 0; r < 32; ++r) {
+            const u64 Pr = readlane64(Pl, r), Pq = readlane64(Pl, 62 - r);
+            const float wr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), r));
+            const float wq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), 62 - r));
+            const bool up = lane > r;
+            const bool active = up || r < 31;        // at r = 31 the lower half would repeat i = 31
+            const u64 D = S.d0 ^ (up ? (Pr ^ Pl) : (Pq ^ Pm));
+            const float M = up ? (wr + wl) : (wq + wm);            // |y'_i| + |y'_j|, i < j
+            const float c = tep_cost(L, M, D);
+            const int ci = up ? r : 62 - r, cj = up ? lane : 63 - lane;
+            if (active && c <= best) {
+                // equal metrics are ordered by table rank (practically never taken)
+                if (c < best || tep2_rank(ci, cj, base2) < tep2_rank(bi, bj, base2)) { best = c; bi = ci; bj = cj; bestD = D; }
+            }
+        }
+        int bestt = tep2_rank(bi, bj, base2);
+        u64 bestE = (bi >= 0 ? 1ull << bi : 0ull) | (bj >= 0 ? 1ull << bj : 0ull);
+        wave_argmin(best, bestt, bestD, bestE, lane);
+        search_finish(L, S, bestE, bestD, f, lane, cw_out);
+        if (lane == 0) {
+            if (metric_out) metric_out[f] = best;
+            if (best_out) best_out[f] = bestt;
+            if (ntep_out) ntep_out[f] = 2081;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // FS-OSD (fs_osd, FS_OSD/fs_testing.py:129-161): order-by-order scan in the order of
 // generate_sequential_teps (:32-49) with two Hamming-distance rules (one_tep_compare :51-64):
 //   HD < tau_e            -> stop everything (the candidate is appended to optimal_list, :143-146)
@@ -723,6 +798,7 @@ __global__ __launch_bounds__(256) void osd_counts_kernel(const u64 *__restrict__
 struct OsdState {
     int64_t ntep[4] = {0, 0, 0, 0};
     uchar4 *d_tep_fs = nullptr;       // FS visit order, weight classes 1..3 back to back
+    int *d_base2 = nullptr;           // order-2 ranks: number of index pairs with a larger sum
     double *d_cdf_half = nullptr;     // PB-OSD: P[Bin(64, 1/2) <= b], b = 0..64
     double *d_coef = nullptr;         // PB-OSD: (64-i)/(i+1)
     void *d_pb_spill = nullptr;       // PB-OSD frontier overflow [waves][stride]
@@ -777,6 +853,17 @@ int osd_ctx_init(ldpc_ctx *ctx)
     }
     LDPC_HIP(hipMalloc((void **)&st->d_tep_fs, fs.size()));
     LDPC_HIP(hipMemcpy(st->d_tep_fs, fs.data(), fs.size(), hipMemcpyHostToDevice));
+    {
+        int base2[127];
+        auto npairs = [](int t) { return (t - 1) / 2 - (t > 63 ? t - 63 : 0) + 1; };
+        for (int sidx = 0; sidx < 127; ++sidx) {
+            int acc = 0;
+            for (int t = sidx + 1; t <= 125; ++t) acc += npairs(t);
+            base2[sidx] = acc;
+        }
+        LDPC_HIP(hipMalloc((void **)&st->d_base2, sizeof(base2)));
+        LDPC_HIP(hipMemcpy(st->d_base2, base2, sizeof(base2), hipMemcpyHostToDevice));
+    }
     // PB-OSD constants, same float64 recurrence as the kernel / oracle
     {
         double coef[64], cdf[65], t = 0.5;
@@ -802,6 +889,7 @@ void osd_ctx_release(ldpc_ctx *ctx)
         (void)hipFree(st->d_perm);
         (void)hipFree(st->d_parity);
         (void)hipFree(st->d_tep_fs);
+        (void)hipFree(st->d_base2);
         (void)hipFree(st->d_cdf_half);
         (void)hipFree(st->d_coef);
         (void)hipFree(st->d_pb_spill);
@@ -917,7 +1005,10 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
         hipLaunchKernelGGL(osd_fs_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
                            d_perm, d_parity, st->d_tep_fs, fp, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
                            d_ntep);
-    } else {
+    } else if (p->order == 2 && !p->reserved) {
+        hipLaunchKernelGGL(osd_search2_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
+                           d_perm, d_parity, st->d_base2, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
+    } else {   // table-driven scan: any order (and order 2 when params->reserved = 1, the cross-check path)
         hipLaunchKernelGGL(osd_search_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
                            d_perm, d_parity, reinterpret_cast<const uchar4 *>(ctx->d_tep), (int)st->ntep[p->order],
                            reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);

@@ -174,3 +174,23 @@ def test_full_size_osd_properties(dec):
     # ML property: the true codeword is never strictly better than a correct OSD answer
     true_metric = (((cw[idx] != (ysel <= 0).to(torch.float32)).double()) * ysel.abs().double()).sum(1)
     assert (out2["metric"][:nf].double() <= true_metric * (1 + 1e-5) + 1e-5)[bits2.eq(cw[idx]).all(1)].all()
+
+
+def test_order2_register_kernel_equals_table_scan_with_ties(dec):
+    """The register-resident order-2 kernel against the table-driven scan and the oracle on inputs
+    where many TEPs have EQUAL metrics (quantised |y|), so 'first minimum in table order' matters."""
+    rng = np.random.default_rng(44)
+    y, cw = np_oracle.make_frames(dec.code.G, 2.0, 600, rng)
+    y[:200] = np.sign(y[:200]) * np.maximum(np.round(np.abs(y[:200]) * 2) / 2, 0.5)   # |y| in {0.5, 1, 1.5, ...}
+    y[200:300] = np.sign(y[200:300])                                                   # all |y| = 1
+    y[300:320] = np.where(rng.random((20, 128)) < 0.5, 1.0, -1.0).astype(np.float32) * 0.25
+    yd = to_dev(y, dec)
+    a = dec.osd_decode(yd, 2)
+    b = dec.osd_decode(yd, 2, params=dec.osd_params(2, table_scan=True))
+    torch.cuda.synchronize()
+    for k in ("cw", "metric", "best", "ntep"):
+        assert torch.equal(a[k], b[k]), k
+    ref = c_oracle.conv_osd(dec.code.G, y, cw, 2)
+    assert np.array_equal(a["best"].cpu().numpy(), ref["best"])
+    assert np.array_equal(words_np(a["cw"]), pack_np(ref["codeword"]))
+    assert np.array_equal(a["metric"].cpu().numpy(), ref["metric"])
