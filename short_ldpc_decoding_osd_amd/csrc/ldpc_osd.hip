@@ -22,6 +22,7 @@
 //                      = flipped-MRB weights + 8 LUT terms in a FIXED order (the canonical order
 //                      the oracle uses, see oracle/np_oracle.py weighted_distance), first minimum.
 #include <math.h>
+#include <stdlib.h>
 
 #include "ldpc_internal.h"
 
@@ -127,14 +128,23 @@ __device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1,
             r = __builtin_ctzll(bal);
         }
         const int pr = __builtin_amdgcn_readlane(rho, r);
-        if (r != i) {
+        if (r != i) {   // exchange logical rows i and r: two lanes of the row map, no data moves
             const int pi = __builtin_amdgcn_readlane(rho, i);
-            if (lane == i) rho = pr;
-            if (lane == r) rho = pi;
+            // (lane select through M0: a VALU instruction may read only one SGPR on gfx9)
+            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(rho) : "s"(pr), "s"(i) : "m0");
+            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(rho) : "s"(pi), "s"(r) : "m0");
         }
         const u64 e = cj & ~(1ull << pr);
-        if ((C1 >> pr) & 1) C1 ^= e;
-        if ((C2 >> pr) & 1) C2 ^= e;
+        if (e != 0) {   // nothing to clear when the pivot column is already a unit vector (common: G = [P | I])
+            const unsigned bit = 1u << (pr & 31);
+            if (pr < 32) {   // wave-uniform: test the half that holds physical row pr without a 64-bit shift
+                if ((unsigned)C1 & bit) C1 ^= e;
+                if ((unsigned)C2 & bit) C2 ^= e;
+            } else {
+                if ((unsigned)(C1 >> 32) & bit) C1 ^= e;
+                if ((unsigned)(C2 >> 32) & bit) C2 ^= e;
+            }
+        }
     }
     return nsw;
 }
@@ -173,6 +183,12 @@ struct __attribute__((aligned(16))) FrontLds {
     unsigned char rowsrc[64];
 };
 
+// r += (k > a) as v_cmp_gt_i32 + v_addc through VCC (both 4-byte encodings)
+__device__ __forceinline__ void rank_gt(int &r, int a, int k)
+{
+    asm("v_cmp_gt_i32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(r) : "v"(a), "v"(k) : "vcc");
+}
+
 __device__ __forceinline__ int below_mask(const unsigned (&m)[4], int x)
 {
     // number of set bits of the 128-bit mask strictly below position x
@@ -207,19 +223,33 @@ __global__ __launch_bounds__(256) void osd_front_kernel(const float *__restrict_
         L.abits[lane] = a1;
         L.abits[lane + 64] = a2;
         wave_fence();
+        // rank = number of keys that sort before mine.  Fast path: strict integer compares only
+        // (v_cmp + v_addc through VCC, 2 instructions per key and element); equal keys then collide
+        // on a rank, which the read-back below detects, and only such frames (exact float ties,
+        // ~5e-4 of random frames) redo the count with the full "lower index first" rule.
         int r1 = 0, r2 = 0;
-        // "u before v"  <=>  a_u > a_v  or  (a_u == a_v and u < v)   (integer order == float order for |y|)
-#pragma unroll 4
+#pragma unroll 8
         for (int u4 = 0; u4 < 32; ++u4) {
             const int4 kq = *reinterpret_cast<const int4 *>(&L.abits[u4 * 4]);
-            const int kk[4] = {kq.x, kq.y, kq.z, kq.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int u = u4 * 4 + q;
-                r1 += (kk[q] > a1) || (kk[q] == a1 && u < lane);
-                r2 += (kk[q] > a2) || (kk[q] == a2 && u < lane + 64);
+            rank_gt(r1, a1, kq.x); rank_gt(r2, a2, kq.x);
+            rank_gt(r1, a1, kq.y); rank_gt(r2, a2, kq.y);
+            rank_gt(r1, a1, kq.z); rank_gt(r2, a2, kq.z);
+            rank_gt(r1, a1, kq.w); rank_gt(r2, a2, kq.w);
+        }
+        L.pi1[r1] = (unsigned char)lane;
+        L.pi1[r2] = (unsigned char)(lane + 64);
+        wave_fence();
+        if (__ballot(L.pi1[r1] != lane || L.pi1[r2] != lane + 64)) {
+            wave_fence();
+            r1 = 0; r2 = 0;
+            // "u before v"  <=>  a_u > a_v  or  (a_u == a_v and u < v)
+            for (int u = 0; u < 128; ++u) {
+                const int ku = L.abits[u];
+                r1 += (ku > a1) || (ku == a1 && u < lane);
+                r2 += (ku > a2) || (ku == a2 && u < lane + 64);
             }
         }
+        wave_fence();
         L.pi1[r1] = (unsigned char)lane;
         L.pi1[r2] = (unsigned char)(lane + 64);
         if (lane < 4) L.mask[lane] = 0;
@@ -291,22 +321,30 @@ __device__ __forceinline__ SearchFrame search_prepare(SearchLds &L, const float 
     S.hm = __ballot(!(y1 > 0.0f));
     S.hp = __ballot(!(y2 > 0.0f));
     wave_fence();
-    // byte LUTs: lane (b = lane/8, g = lane%8) fills entries v = 32 g + r, r = 0..31
+    // byte LUTs, lut[b][v] = sum over the set bits t of v (ascending t) of |y'[64 + 8 b + t]|.
+    // Lane l owns the entries whose low five index bits equal l & 31 and whose top index bit equals
+    // l >> 5 (4 x 8 = 32 entries): within each 32-lane LDS group the stores of one instruction then
+    // hit 32 distinct banks.  (Letting a lane fill 32 CONSECUTIVE entries puts all 64 lanes on one
+    // bank per store: 32-way conflicts, which cost as much LDS time as all the lookups of the scan.)
     {
-        const int b = lane >> 3, g = lane & 7;
-        float wt[8];
+        const int lo5 = lane & 31, top = lane >> 5;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) wt[t] = L.w[64 + 8 * b + t];
-        float R[32];
-        R[0] = 0.0f;
+        for (int b = 0; b < 8; ++b) {
+            const float4 wa = *reinterpret_cast<const float4 *>(&L.w[64 + 8 * b]);       // broadcast reads
+            const float4 wb = *reinterpret_cast<const float4 *>(&L.w[64 + 8 * b + 4]);
+            float base = 0.0f;
+            base = base + ((lo5 & 1) ? wa.x : 0.0f);
+            base = base + ((lo5 & 2) ? wa.y : 0.0f);
+            base = base + ((lo5 & 4) ? wa.z : 0.0f);
+            base = base + ((lo5 & 8) ? wa.w : 0.0f);
+            base = base + ((lo5 & 16) ? wb.x : 0.0f);
+            const float h7 = top ? wb.w : 0.0f;
 #pragma unroll
-        for (int t = 0; t < 5; ++t)
-#pragma unroll
-            for (int r = 1 << t; r < (2 << t); ++r) R[r] = R[r - (1 << t)] + wt[t];
-        const float h5 = (g & 1) ? wt[5] : 0.0f, h6 = (g & 2) ? wt[6] : 0.0f, h7 = (g & 4) ? wt[7] : 0.0f;
-        float *dst = &L.lut[b][g * 32];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) dst[r] = ((R[r] + h5) + h6) + h7;
+            for (int h = 0; h < 4; ++h) {   // index bits 5, 6 = h, bit 7 = top
+                const float v5 = (h & 1) ? wb.y : 0.0f, v6 = (h & 2) ? wb.z : 0.0f;
+                L.lut[b][(top * 4 + h) * 32 + lo5] = ((base + v5) + v6) + h7;
+            }
+        }
     }
     // d0 = (u0 . P') ^ h_parity : XOR-reduce the rows selected by the MRB hard decisions
     u64 sel = ((S.hm >> lane) & 1) ? Prow : 0ull;
@@ -408,6 +446,7 @@ __device__ __forceinline__ int tep2_rank(int bi, int bj, const int *__restrict__
     return 65 + base2[s] + bi - (s > 63 ? s - 63 : 0);
 }
 
+template <bool PRUNE>
 __global__ __launch_bounds__(256) void osd_search2_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                           const int *__restrict__ count, long long F,
                                                           const unsigned char *__restrict__ perm_in,
@@ -437,19 +476,32 @@ __global__ __launch_bounds__(256) void osd_search2_kernel(const float *__restric
             const float c = tep_cost(L, wl, D);
             if (c < best) { best = c; bj = lane; bestD = D; }      // a tie keeps the lower rank (order 0)
         }
+        // exact pruning: a TEP whose flipped-MRB weight alone exceeds the best metric found so far by
+        // ANY lane can neither win nor tie (the parity terms only add), so its LUT reads are skipped;
+        // masked-off lanes also stay out of the LDS bank arbitration.  bestU is refreshed every 8 rounds.
+        float bestU = best;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bestU = __builtin_fminf(bestU, __shfl(bestU, lane ^ off, 64));
         for (int r = 0; r < 32; ++r) {
             const u64 Pr = readlane64(Pl, r), Pq = readlane64(Pl, 62 - r);
             const float wr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), r));
             const float wq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), 62 - r));
             const bool up = lane > r;
             const bool active = up || r < 31;        // at r = 31 the lower half would repeat i = 31
-            const u64 D = S.d0 ^ (up ? (Pr ^ Pl) : (Pq ^ Pm));
             const float M = up ? (wr + wl) : (wq + wm);            // |y'_i| + |y'_j|, i < j
-            const float c = tep_cost(L, M, D);
-            const int ci = up ? r : 62 - r, cj = up ? lane : 63 - lane;
-            if (active && c <= best) {
+            if (active && (!PRUNE || !(M > bestU))) {
+                const u64 D = S.d0 ^ (up ? (Pr ^ Pl) : (Pq ^ Pm));
+                const float c = tep_cost(L, M, D);
+                const int ci = up ? r : 62 - r, cj = up ? lane : 63 - lane;
                 // equal metrics are ordered by table rank (practically never taken)
-                if (c < best || tep2_rank(ci, cj, base2) < tep2_rank(bi, bj, base2)) { best = c; bi = ci; bj = cj; bestD = D; }
+                if (c < best || (c == best && tep2_rank(ci, cj, base2) < tep2_rank(bi, bj, base2))) {
+                    best = c; bi = ci; bj = cj; bestD = D;
+                }
+            }
+            if (PRUNE && (r & 7) == 7) {
+                bestU = __builtin_fminf(bestU, best);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) bestU = __builtin_fminf(bestU, __shfl(bestU, lane ^ off, 64));
             }
         }
         int bestt = tep2_rank(bi, bj, base2);
@@ -1006,7 +1058,8 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
                            d_perm, d_parity, st->d_tep_fs, fp, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
                            d_ntep);
     } else if (p->order == 2 && !p->reserved) {
-        hipLaunchKernelGGL(osd_search2_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
+        static const bool prune = getenv("LDPC_OSD_PRUNE") && atoi(getenv("LDPC_OSD_PRUNE")) != 0;
+        hipLaunchKernelGGL(prune ? osd_search2_kernel<true> : osd_search2_kernel<false>, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
                            d_perm, d_parity, st->d_base2, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
     } else {   // table-driven scan: any order (and order 2 when params->reserved = 1, the cross-check path)
         hipLaunchKernelGGL(osd_search_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
