@@ -6,7 +6,7 @@ NMS-10 (+ OSD-p on the syndrome-failed frames) at Eb/N0 = 2.5 dB on synthetic AW
 
 One "step" = one pass of the hot path over one device-resident batch of frames:
 NMS-10 -> failed-frame compaction -> OSD-p on the failures -> error counters, all on the GPU
-with no host round trip.  Inputs are generated on the device before the timed region.
+with no host round trip, enqueued by ONE call into the C ABI (ldpc_pipeline_run).  Inputs are generated on the device before the timed region.
 For N > 1 the driver launches one rank per GPU (torch.distributed, backend nccl = RCCL);
 frames shard across ranks (weak scaling: fixed per-GPU batch) and the only collective is ONE
 all-reduce of the error counters per measurement, inside the timed region.
@@ -64,45 +64,22 @@ def make_frames(dec, B, seed):
     return y, labels
 
 
-class Step:
-    """Pre-allocated buffers + the launch sequence of one hot-path pass."""
-
-    def __init__(self, dec, y, labels, order):
-        self.dec, self.y, self.labels, self.order = dec, y, labels, order
-        B = y.shape[0]
-        self.B = B
-        self.nms_out = dict(soft=dec.empty((B, dec.n), torch.float32), hard=dec.empty((B, dec.words), torch.int64),
-                            fail=dec.empty((B,), torch.uint8))
-        self.index = dec.empty((B,), torch.int32)
-        self.count = dec.empty((1,), torch.int32)
-        self.nms_counts = torch.zeros(5, dtype=torch.int64, device=dec.device)
-        self.osd_counts = torch.zeros(3, dtype=torch.int64, device=dec.device)
-        if order is not None:
-            self.osd_out = dict(cw=dec.empty((B, 2), torch.int64), metric=dec.empty((B,), torch.float32),
-                                best=dec.empty((B,), torch.int32), ntep=dec.empty((B,), torch.int32))
-        self.ev = []  # (start, end) HIP events around the dominant kernels, on the launch stream
-
-    def run(self, timed_events=False):
-        d = self.dec
-        if timed_events:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        d.nms(self.y, T_ITERS, ALPHA, want_soft=True, want_hard=True, want_fail=True, out=self.nms_out)
-        if timed_events:
-            e1.record()
-        d.eval_counts(self.nms_out["hard"], self.labels, self.nms_out["fail"], counts=self.nms_counts)
-        if self.order is not None:
-            d.compact(self.nms_out["fail"], index=self.index, count=self.count)
-            if timed_events:
-                e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e2.record()
-            d.osd_decode(self.y, self.order, index=self.index, count=self.count, F=self.B, out=self.osd_out)
-            if timed_events:
-                e3.record()
-            d.osd_counts(self.osd_out["cw"], self.labels, index=self.index, count=self.count,
-                         ntep=self.osd_out["ntep"], counts=self.osd_counts, F=self.B)
-        if timed_events:
-            self.ev.append((e0, e1) + ((e2, e3) if self.order is not None else ()))
+def pmc_traffic(kernel, workload, B):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes) -- only when the
+    profile was taken on this very workload; otherwise null."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_counters_*.json")), reverse=True):
+        try:
+            prof = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if prof.get("bench_workload") != workload or prof.get("frames_per_launch") != B:
+            continue
+        for name, counters in prof.get("per_launch_mean", {}).items():
+            if kernel in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+                return (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+    return None
 
 
 def cpu_baseline(code_G, code_H, order, seconds_target=15.0):
@@ -163,21 +140,21 @@ def main():
     B = args.batch or default_batch
     dec = Decoder(Code(), local_rank)
     y, labels = make_frames(dec, B, seed=20241020 + rank)
-    step = Step(dec, y, labels, order)
+    from short_ldpc_decoding_osd_amd._lib import TIMING_SLOTS
+    from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline
+    step = BatchPipeline(dec, B, T_ITERS, ALPHA, osd_order=order).bind(y, labels)
 
     for _ in range(args.warmup):
         step.run()
-    step.nms_counts.zero_()
-    step.osd_counts.zero_()
+    step.reset_counters()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step.run(timed_events=True)
-    counters = torch.cat([step.nms_counts, step.osd_counts])
-    counters = allreduce_counters(counters)           # the path's one exchange step (RCCL over xGMI)
+    for k in range(args.steps):
+        step.run(timing_slot=k % TIMING_SLOTS)         # library-side HIP events around the hot kernels
+    counters = allreduce_counters(step.counters())    # the path's one exchange step (RCCL over xGMI)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -213,20 +190,25 @@ def main():
 
     if rank == 0:
         # roofline of the dominant kernel from the HIP events recorded on the launch stream
-        nms_ms = float(np.mean([a.elapsed_time(b) for a, b, *_ in step.ev]))
-        kern = {"nms": (nms_ms, NMS_BYTES_PER_FRAME * B)}
+        tm = np.array([step.timing(k) for k in range(min(args.steps, TIMING_SLOTS))])
+        nms_name = {1: "nms_generic_kernel", 2: "nms_qc16_kernel"}[dec.nms_kernel]
+        kern = {nms_name: (float(tm[:, 0].mean()), NMS_BYTES_PER_FRAME * B)}
         if order is not None:
-            osd_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in step.ev]))
             f_per_step = c[5] / (args.steps * world)
-            kern["osd"] = (osd_ms, OSD_BYTES_PER_FRAME * f_per_step)
+            # front end: 512 B channel values in + 640 B workspace out; search: 1152 B in + 24 B out;
+            # together the 536 B/frame of SURVEY 8(d) plus the workspace round trip between the two kernels
+            kern["osd_front_kernel"] = (float(tm[:, 1].mean()), (512 + 640) * f_per_step)
+            kern["osd_search2_kernel" if order == 2 else "osd_search_kernel"] = (float(tm[:, 2].mean()), (1152 + 24) * f_per_step)
         name = max(kern, key=lambda k: kern[k][0])
         ms, nbytes = kern[name]
         achieved = nbytes / (ms * 1e-3) / 1e9
         res["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(name, args.workload, B), "avg_launch_ms": ms,
                            "algorithmic_bytes_per_launch": float(nbytes),
                            "all_kernels_ms": {k: v[0] for k, v in kern.items()},
-                           "note": "VALU-issue bound path (no contraction, no MFMA); HBM fraction reported as mandated"}
+                           "all_kernels_GBps": {k: v[1] / (v[0] * 1e-3) / 1e9 for k, v in kern.items()},
+                           "note": "no contraction on this path (no MFMA); NMS and the OSD front end are VALU-issue bound, "
+                                   "the OSD search LDS bound -- see DESIGN.md 5; HBM fraction reported as mandated"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(dec.code.G, dec.code.H, order)
         print(json.dumps(res), flush=True)

@@ -207,6 +207,44 @@ int ldpc_osd_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
 int ldpc_osd_counts(ldpc_ctx *ctx, const uint64_t *d_cw, const uint64_t *d_label_bits, const int32_t *d_index,
                     const int32_t *d_count, const int32_t *d_ntep, int64_t F, int64_t *d_counts, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * One batch through the whole path with a single host call: the body of the reference drivers'
+ * per-batch loops (ldpc_128_testing.py:117-131 then pb_testing.py / fs_testing.py per failed frame):
+ *   NMS-T -> error counters -> failed-frame compaction -> OSD (front end + search) on the failures
+ *   -> OSD counters.
+ * Exactly the sequence ldpc_nms_decode, ldpc_eval_counts, ldpc_compact, ldpc_osd_front,
+ * ldpc_osd_search, ldpc_osd_counts on one stream, without a host round trip in between (the OSD
+ * kernels read the failure count on the device).  Nullable members switch their stage off.
+ * With timing_slot >= 0 the library brackets the three hot kernels with its own HIP events on
+ * `stream`; after synchronising, ldpc_pipeline_timing returns their durations.
+ * ------------------------------------------------------------------------------------- */
+typedef struct ldpc_pipeline {
+    const float *d_llr;            /* [B][n]                                               */
+    int64_t B;
+    int32_t T, nms_kernel;
+    const float *alpha;            /* host [T]                                             */
+    float w_in, w_out;
+    float *d_soft;                 /* [B][n] nullable                                      */
+    uint64_t *d_hard;              /* [B][n/64]                                            */
+    uint8_t *d_fail;               /* [B]                                                  */
+    const uint64_t *d_label_bits;  /* [B][n/64] nullable: no counters                      */
+    int64_t *d_nms_counts;         /* [5] accumulated, nullable                            */
+    int32_t osd_enable, timing_slot;
+    ldpc_osd_params osd;
+    int32_t *d_index, *d_count;    /* [B], [1]                                             */
+    uint8_t *d_perm;               /* [B][128]                                             */
+    uint64_t *d_parity;            /* [B][64]                                              */
+    uint64_t *d_cw;                /* [B][2]                                               */
+    float *d_metric;               /* [B] nullable                                         */
+    int32_t *d_best, *d_ntep;      /* [B] nullable / [B]                                   */
+    int64_t *d_osd_counts;         /* [3] accumulated, nullable                            */
+} ldpc_pipeline;
+
+#define LDPC_TIMING_SLOTS 64
+int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream);
+/* ms[3] = {NMS, OSD front end, OSD search} of the run that used `slot` (call after the stream is idle) */
+int ldpc_pipeline_timing(ldpc_ctx *ctx, int32_t slot, float *ms);
+
 #ifdef __cplusplus
 }
 #endif

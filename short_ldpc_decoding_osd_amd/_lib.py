@@ -19,6 +19,7 @@ SYMBOLS = (
     "ldpc_ctx_create", "ldpc_ctx_destroy", "ldpc_ctx_nms_kernel",
     "ldpc_nms_decode", "ldpc_eval_counts", "ldpc_compact", "ldpc_pack_bits", "ldpc_unpack_bits",
     "ldpc_osd_reserve", "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_search", "ldpc_osd_decode", "ldpc_osd_counts",
+    "ldpc_pipeline_run", "ldpc_pipeline_timing",
 )
 
 NMS_AUTO, NMS_GENERIC, NMS_QC16 = 0, 1, 2
@@ -29,6 +30,21 @@ class OsdParams(C.Structure):
     _fields_ = [("order", C.c_int32), ("algo", C.c_int32), ("snr_db", C.c_float), ("fs_beta", C.c_float),
                 ("fs_tau_e", C.c_float), ("fs_tau_psc", C.c_float), ("fs_reference_quirk", C.c_int32),
                 ("reserved", C.c_int32), ("d_aux", C.c_void_p)]
+
+
+class Pipeline(C.Structure):
+    """ldpc_pipeline of include/ldpc_osd.h (device pointers as integers)."""
+    _fields_ = [("d_llr", C.c_void_p), ("B", C.c_int64), ("T", C.c_int32), ("nms_kernel", C.c_int32),
+                ("alpha", C.POINTER(C.c_float)), ("w_in", C.c_float), ("w_out", C.c_float),
+                ("d_soft", C.c_void_p), ("d_hard", C.c_void_p), ("d_fail", C.c_void_p),
+                ("d_label_bits", C.c_void_p), ("d_nms_counts", C.c_void_p),
+                ("osd_enable", C.c_int32), ("timing_slot", C.c_int32), ("osd", OsdParams),
+                ("d_index", C.c_void_p), ("d_count", C.c_void_p), ("d_perm", C.c_void_p), ("d_parity", C.c_void_p),
+                ("d_cw", C.c_void_p), ("d_metric", C.c_void_p), ("d_best", C.c_void_p), ("d_ntep", C.c_void_p),
+                ("d_osd_counts", C.c_void_p)]
+
+
+TIMING_SLOTS = 64
 
 
 class LdpcError(RuntimeError):
@@ -78,6 +94,8 @@ def load():
         "ldpc_osd_search": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, C.POINTER(OsdParams), vp, vp, vp, vp, vp]),
         "ldpc_osd_decode": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(OsdParams), vp, vp, vp, vp, vp]),
         "ldpc_osd_counts": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, vp]),
+        "ldpc_pipeline_run": (C.c_int, [vp, C.POINTER(Pipeline), vp]),
+        "ldpc_pipeline_timing": (C.c_int, [vp, i32, C.POINTER(f32)]),
     }
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError here = ABI/header drift, which must be loud

@@ -62,6 +62,10 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx)
     (void)hipFree(ctx->d_chk_ptr); (void)hipFree(ctx->d_chk_var);
     (void)hipFree(ctx->d_var_ptr); (void)hipFree(ctx->d_var_edge);
     (void)hipFree(ctx->d_blocksum);
+    if (ctx->timing) {
+        for (int i = 0; i < LDPC_TIMING_SLOTS * 6; ++i) (void)hipEventDestroy(ctx->timing[i]);
+        delete[] ctx->timing;
+    }
     delete ctx;
 }
 
@@ -80,6 +84,56 @@ int ldpc_nms_decode(ldpc_ctx *ctx, const float *d_llr, int64_t B, int32_t T, con
     if (T > 0 && !alpha) return fail(LDPC_E_ARG, "ldpc_nms_decode: alpha is NULL");
     if (B == 0) return LDPC_OK;
     return launch_nms(ctx, d_llr, B, T, alpha, w_in, w_out, d_soft, d_traj, d_hard, d_fail, kernel, (hipStream_t)stream);
+}
+
+int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
+{
+    if (!ctx || !p) return fail(LDPC_E_ARG, "ldpc_pipeline_run: null argument");
+    if (!p->d_hard || !p->d_fail) return fail(LDPC_E_ARG, "ldpc_pipeline_run: d_hard and d_fail are required");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t *ev = nullptr;
+    if (p->timing_slot >= 0) {
+        if (p->timing_slot >= LDPC_TIMING_SLOTS) return fail(LDPC_E_ARG, "ldpc_pipeline_run: timing_slot %d", p->timing_slot);
+        if (!ctx->timing) {
+            ctx->timing = new hipEvent_t[LDPC_TIMING_SLOTS * 6];
+            for (int i = 0; i < LDPC_TIMING_SLOTS * 6; ++i) LDPC_HIP(hipEventCreate(&ctx->timing[i]));
+        }
+        ev = ctx->timing + p->timing_slot * 6;
+    }
+    int rc;
+    if (ev) LDPC_HIP(hipEventRecord(ev[0], s));
+    if ((rc = ldpc_nms_decode(ctx, p->d_llr, p->B, p->T, p->alpha, p->w_in, p->w_out, p->d_soft, nullptr, p->d_hard,
+                              p->d_fail, p->nms_kernel, stream))) return rc;
+    if (ev) LDPC_HIP(hipEventRecord(ev[1], s));
+    if (p->d_label_bits && p->d_nms_counts &&
+        (rc = ldpc_eval_counts(ctx, p->d_hard, p->d_label_bits, p->d_fail, p->B, p->d_nms_counts, stream))) return rc;
+    if (p->osd_enable) {
+        if (!p->d_index || !p->d_count || !p->d_perm || !p->d_parity || !p->d_cw)
+            return fail(LDPC_E_ARG, "ldpc_pipeline_run: OSD stage needs d_index, d_count, d_perm, d_parity, d_cw");
+        if ((rc = ldpc_compact(ctx, p->d_fail, p->B, p->d_index, p->d_count, stream))) return rc;
+        if (ev) LDPC_HIP(hipEventRecord(ev[2], s));
+        if ((rc = ldpc_osd_front(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, nullptr, stream))) return rc;
+        if (ev) LDPC_HIP(hipEventRecord(ev[3], s));
+        if ((rc = ldpc_osd_search(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, &p->osd, p->d_cw,
+                                  p->d_metric, p->d_best, p->d_ntep, stream))) return rc;
+        if (ev) LDPC_HIP(hipEventRecord(ev[4], s));
+        if (p->d_label_bits && p->d_osd_counts &&
+            (rc = ldpc_osd_counts(ctx, p->d_cw, p->d_label_bits, p->d_index, p->d_count, p->d_ntep, p->B, p->d_osd_counts,
+                                  stream))) return rc;
+    }
+    return LDPC_OK;
+}
+
+int ldpc_pipeline_timing(ldpc_ctx *ctx, int32_t slot, float *ms)
+{
+    if (!ctx || !ms || slot < 0 || slot >= LDPC_TIMING_SLOTS || !ctx->timing)
+        return fail(LDPC_E_ARG, "ldpc_pipeline_timing: no timed run in slot %d", slot);
+    hipEvent_t *ev = ctx->timing + slot * 6;
+    ms[0] = ms[1] = ms[2] = 0.0f;
+    LDPC_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+    if (hipEventElapsedTime(&ms[1], ev[2], ev[3]) != hipSuccess) { ms[1] = 0.0f; (void)hipGetLastError(); }
+    if (hipEventElapsedTime(&ms[2], ev[3], ev[4]) != hipSuccess) { ms[2] = 0.0f; (void)hipGetLastError(); }
+    return LDPC_OK;
 }
 
 }  // extern "C"

@@ -59,6 +59,7 @@ struct ldpc_ctx {
     bool dpp_ror_up = true;        // probed: row_ror:n moves data towards higher lanes
     bool osd_ok = false;
     void *osd_state = nullptr;     // ldpc::OsdState (TEP table sizes, front-end workspace)
+    hipEvent_t *timing = nullptr;  // [LDPC_TIMING_SLOTS][6] events of ldpc_pipeline_run, created on first use
 };
 
 namespace ldpc {

@@ -90,15 +90,15 @@ __device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1,
                                           unsigned char *swaps /* LDS or global [64][2], may be null */)
 {
     int nsw = 0;
-    for (int i = 0; i < kOsdK; ++i) {
+    u64 ge_i = ~0ull;   // lanes (logical rows) >= i
+    for (unsigned i = 0; i < (unsigned)kOsdK; ++i, ge_i <<= 1) {
         u64 cj = readlane64(C1, i);
-        const u64 ge_i = ~0ull << i;
-        u64 bal = __ballot((cj >> rho) & 1) & ge_i;
-        int r;
+        const u64 bal = __ballot((cj >> rho) & 1) & ge_i;
+        unsigned r;
         if (bal == 0) {
             const int pri = __builtin_amdgcn_readlane(rho, i);
             const u64 b1 = __ballot((C1 >> pri) & 1) & ge_i;
-            int col;
+            unsigned col;
             if (b1) col = __builtin_ctzll(b1);
             else {
                 const u64 b2 = __ballot((C2 >> pri) & 1);
@@ -106,23 +106,23 @@ __device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1,
                 col = 64 + __builtin_ctzll(b2);
             }
             // (select form on purpose: branching on col < 64 makes the compiler spill C1/C2 to scratch)
-            const int cl = col & 63;
+            const unsigned cl = col & 63;
             const bool lo = col < 64;
             const u64 cc1 = readlane64(C1, cl), cc2 = readlane64(C2, cl);
             const int ic1 = __builtin_amdgcn_readlane(idx1, cl), ic2 = __builtin_amdgcn_readlane(idx2, cl);
             const u64 cc = lo ? cc1 : cc2;
             const int ic = lo ? ic1 : ic2;
             const int ii = __builtin_amdgcn_readlane(idx1, i);
-            const bool hit = lane == cl;
+            const bool hit = (unsigned)lane == cl;
             C1 = (hit && lo) ? cj : C1;
             idx1 = (hit && lo) ? ii : idx1;
             C2 = (hit && !lo) ? cj : C2;
             idx2 = (hit && !lo) ? ii : idx2;
-            C1 = (lane == i) ? cc : C1;
-            idx1 = (lane == i) ? ic : idx1;
+            C1 = ((unsigned)lane == i) ? cc : C1;
+            idx1 = ((unsigned)lane == i) ? ic : idx1;
             if (swaps && lane == 0) { swaps[2 * nsw] = (unsigned char)i; swaps[2 * nsw + 1] = (unsigned char)col; }
             ++nsw;
-            cj = cc;
+            cj = readlane64(C1, i);   // re-read instead of carrying `cc`: keeps the pivot column in SGPRs on both paths
             r = i;
         } else {
             r = __builtin_ctzll(bal);

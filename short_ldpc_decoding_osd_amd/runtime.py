@@ -145,14 +145,17 @@ class Decoder:
                    "ldpc_osd_ge")
         return red, swaps, ns
 
-    def osd_front(self, y, index=None, count=None, F=None):
+    def osd_front(self, y, index=None, count=None, F=None, out=None):
         """Reliability sort + elimination + MRB bookkeeping.  Returns (perm[F,128] u8,
-        parity[F,64] int64 rows of P', nswaps[F] int32)."""
+        parity[F,64] int64 rows of P', nswaps[F] int32); ``out`` may carry those three preallocated."""
         self._chk(y, torch.float32, (self.n,), "y")
         F = (index.shape[0] if index is not None else y.shape[0]) if F is None else F
-        perm = self.empty((F, 128), torch.uint8)
-        parity = self.empty((F, 64), torch.int64)
-        ns = self.empty((F,), torch.int32)
+        if out is not None:
+            perm, parity, ns = out
+        else:
+            perm = self.empty((F, 128), torch.uint8)
+            parity = self.empty((F, 64), torch.int64)
+            ns = self.empty((F,), torch.int32)
         _lib.check(self.L.ldpc_osd_front(self._ctx, _ptr(y), _ptr(index), _ptr(count), F, _ptr(perm), _ptr(parity),
                                          _ptr(ns), self._stream()), "ldpc_osd_front")
         return perm, parity, ns

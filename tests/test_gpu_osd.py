@@ -194,3 +194,40 @@ def test_order2_register_kernel_equals_table_scan_with_ties(dec):
     assert np.array_equal(a["best"].cpu().numpy(), ref["best"])
     assert np.array_equal(words_np(a["cw"]), pack_np(ref["codeword"]))
     assert np.array_equal(a["metric"].cpu().numpy(), ref["metric"])
+
+
+def test_single_call_pipeline_equals_the_separate_calls(dec):
+    """ldpc_pipeline_run == ldpc_nms_decode + eval + compact + osd_front + osd_search + osd_counts."""
+    from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline
+    rng = np.random.default_rng(71)
+    y, cw = np_oracle.make_frames(dec.code.G, 2.5, 5000, rng)
+    yd, lab = to_dev(y, dec), dec.pack_bits(to_dev(cw, dec))
+    pipe = BatchPipeline(dec, 5000, 10, ALPHA0, osd_order=2).bind(yd, lab)
+    pipe.run(timing_slot=3)
+    pipe.run()
+    torch.cuda.synchronize()
+    res = dec.nms(yd, 10, ALPHA0)
+    index, count = dec.compact(res["fail"])
+    nf = int(count.cpu()[0])
+    out = dec.osd_decode(yd, 2, index=index, count=count, F=5000)
+    torch.cuda.synchronize()
+    assert torch.equal(pipe.soft, res["soft"]) and torch.equal(pipe.hard, res["hard"]) and torch.equal(pipe.fail, res["fail"])
+    assert int(pipe.count.cpu()[0]) == nf and torch.equal(pipe.index[:nf], index[:nf])
+    for k, t in (("cw", pipe.cw), ("metric", pipe.metric), ("best", pipe.best), ("ntep", pipe.ntep)):
+        assert torch.equal(t[:nf], out[k][:nf]), k
+    c = pipe.counters().cpu().numpy()
+    ref = c_oracle.conv_osd(dec.code.G, y[index[:nf].cpu().numpy()], cw[index[:nf].cpu().numpy()], 2)
+    assert c[0] == 10000 and c[4] == 2 * nf and c[5] == 2 * nf and c[6] == 2 * int((~ref["correct"]).sum())
+    ms = pipe.timing(3)
+    assert all(0.0 < v < 50.0 for v in ms)
+    # NMS-only pipeline and a PB-OSD pipeline through the same entry point
+    from short_ldpc_decoding_osd_amd import _lib
+    p2 = BatchPipeline(dec, 5000, 10, ALPHA0).bind(yd, lab)
+    p2.run()
+    p3 = BatchPipeline(dec, 5000, 10, ALPHA0, osd_order=2, osd_algo=_lib.OSD_PB, snr_db=2.5).bind(yd, lab)
+    p3.run()
+    torch.cuda.synchronize()
+    assert torch.equal(p2.soft, res["soft"]) and p2.counters().cpu().numpy()[4] == nf
+    refpb = c_oracle.pb_osd(dec.code.G, y[index[:nf].cpu().numpy()], cw[index[:nf].cpu().numpy()], 2, 2.5)
+    assert np.array_equal(p3.ntep[:nf].cpu().numpy(), refpb["num_teps"])
+    assert p3.counters().cpu().numpy()[6] == int((~refpb["correct"]).sum())
