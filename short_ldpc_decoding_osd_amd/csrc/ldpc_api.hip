@@ -92,12 +92,18 @@ int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
     if (!p->d_hard || !p->d_fail) return fail(LDPC_E_ARG, "ldpc_pipeline_run: d_hard and d_fail are required");
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t *ev = nullptr;
-    if (p->timing_slot >= 0) {
-        if (p->timing_slot >= LDPC_TIMING_SLOTS) return fail(LDPC_E_ARG, "ldpc_pipeline_run: timing_slot %d", p->timing_slot);
-        if (!ctx->timing) {
+    if (!ctx->timing) {   // event pool: created on the first pipeline call (any slot), i.e. during warm-up
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone) {
             ctx->timing = new hipEvent_t[LDPC_TIMING_SLOTS * 6];
-            for (int i = 0; i < LDPC_TIMING_SLOTS * 6; ++i) LDPC_HIP(hipEventCreate(&ctx->timing[i]));
+            for (int i = 0; i < LDPC_TIMING_SLOTS * 6; ++i) {
+                LDPC_HIP(hipEventCreate(&ctx->timing[i]));
+                LDPC_HIP(hipEventRecord(ctx->timing[i], s));   // first record of an event is slow (signal set-up): pay it here
+            }
         }
+    }
+    if (p->timing_slot >= 0) {
+        if (p->timing_slot >= LDPC_TIMING_SLOTS || !ctx->timing) return fail(LDPC_E_ARG, "ldpc_pipeline_run: timing_slot %d", p->timing_slot);
         ev = ctx->timing + p->timing_slot * 6;
     }
     int rc;

@@ -23,8 +23,8 @@ class BatchPipeline:
         self.soft = e((B, dec.n), torch.float32) if want_soft else None
         self.hard = e((B, dec.words), torch.int64)
         self.fail = e((B,), torch.uint8)
-        self.nms_counts = torch.zeros(5, dtype=torch.int64, device=dec.device)
-        self.osd_counts = torch.zeros(3, dtype=torch.int64, device=dec.device)
+        self._counts = torch.zeros(8, dtype=torch.int64, device=dec.device)   # one buffer: no torch op to gather them
+        self.nms_counts, self.osd_counts = self._counts[:5], self._counts[5:]
         self._alpha = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=np.float32), (max(T, 1),)))
         p = _lib.Pipeline()
         p.B, p.T, p.nms_kernel = self.B, self.T, _lib.NMS_AUTO
@@ -73,9 +73,8 @@ class BatchPipeline:
         return tuple(float(v) for v in ms)
 
     def reset_counters(self):
-        self.nms_counts.zero_()
-        self.osd_counts.zero_()
+        self._counts.zero_()
 
     def counters(self):
         """int64[8]: {frames, frame_err, bit_err, undetected, synd_fail, osd_frames, osd_wrong, teps}."""
-        return torch.cat([self.nms_counts, self.osd_counts])
+        return self._counts
