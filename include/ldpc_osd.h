@@ -232,8 +232,8 @@ typedef struct ldpc_pipeline {
     int32_t osd_enable, timing_slot;
     ldpc_osd_params osd;
     int32_t *d_index, *d_count;    /* [B], [1]                                             */
-    uint8_t *d_perm;               /* [B][128]                                             */
-    uint64_t *d_parity;            /* [B][64]                                              */
+    uint8_t *d_perm;               /* [B][128] nullable: both NULL = ldpc_osd_decode on the     */
+    uint64_t *d_parity;            /* [B][64]  context workspace (fused kernel for OSD-2)       */
     uint64_t *d_cw;                /* [B][2]                                               */
     float *d_metric;               /* [B] nullable                                         */
     int32_t *d_best, *d_ntep;      /* [B] nullable / [B]                                   */
@@ -242,7 +242,8 @@ typedef struct ldpc_pipeline {
 
 #define LDPC_TIMING_SLOTS 64
 int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream);
-/* ms[3] = {NMS, OSD front end, OSD search} of the run that used `slot` (call after the stream is idle) */
+/* ms[3] = {NMS, OSD front end, OSD search} of the run that used `slot` (call after the stream is idle);
+ * when d_perm/d_parity were NULL the OSD ran through ldpc_osd_decode: ms[1] = 0, ms[2] = whole OSD stage */
 int ldpc_pipeline_timing(ldpc_ctx *ctx, int32_t slot, float *ms);
 
 #ifdef __cplusplus

@@ -114,14 +114,20 @@ int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
     if (p->d_label_bits && p->d_nms_counts &&
         (rc = ldpc_eval_counts(ctx, p->d_hard, p->d_label_bits, p->d_fail, p->B, p->d_nms_counts, stream))) return rc;
     if (p->osd_enable) {
-        if (!p->d_index || !p->d_count || !p->d_perm || !p->d_parity || !p->d_cw)
-            return fail(LDPC_E_ARG, "ldpc_pipeline_run: OSD stage needs d_index, d_count, d_perm, d_parity, d_cw");
+        if (!p->d_index || !p->d_count || !p->d_cw)
+            return fail(LDPC_E_ARG, "ldpc_pipeline_run: OSD stage needs d_index, d_count, d_cw");
         if ((rc = ldpc_compact(ctx, p->d_fail, p->B, p->d_index, p->d_count, stream))) return rc;
         if (ev) LDPC_HIP(hipEventRecord(ev[2], s));
-        if ((rc = ldpc_osd_front(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, nullptr, stream))) return rc;
-        if (ev) LDPC_HIP(hipEventRecord(ev[3], s));
-        if ((rc = ldpc_osd_search(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, &p->osd, p->d_cw,
-                                  p->d_metric, p->d_best, p->d_ntep, stream))) return rc;
+        if (p->d_perm && p->d_parity) {   // caller wants the front-end results: two kernels
+            if ((rc = ldpc_osd_front(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, nullptr, stream))) return rc;
+            if (ev) LDPC_HIP(hipEventRecord(ev[3], s));
+            if ((rc = ldpc_osd_search(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, &p->osd, p->d_cw,
+                                      p->d_metric, p->d_best, p->d_ntep, stream))) return rc;
+        } else {                          // ldpc_osd_decode: fused kernel where one exists (conventional order 2)
+            if (ev) LDPC_HIP(hipEventRecord(ev[3], s));
+            if ((rc = ldpc_osd_decode(ctx, p->d_llr, p->d_index, p->d_count, p->B, &p->osd, p->d_cw, p->d_metric, p->d_best,
+                                      p->d_ntep, stream))) return rc;
+        }
         if (ev) LDPC_HIP(hipEventRecord(ev[4], s));
         if (p->d_label_bits && p->d_osd_counts &&
             (rc = ldpc_osd_counts(ctx, p->d_cw, p->d_label_bits, p->d_index, p->d_count, p->d_ntep, p->B, p->d_osd_counts,

@@ -181,6 +181,13 @@ struct __attribute__((aligned(16))) FrontLds {
     unsigned mask[4];        // 128-bit membership mask of the MRB indices
     unsigned char pi1[128];  // sorted position -> original bit
     unsigned char rowsrc[64];
+    unsigned char perm[128]; // primed position -> original bit
+};
+
+struct FrontResult {
+    int o1, o2;   // original bit index of primed positions lane and 64 + lane
+    u64 Prow;     // row `lane` of P'
+    int ns;       // recorded column exchanges (-1: rank-deficient)
 };
 
 // r += (k > a) as v_cmp_gt_i32 + v_addc through VCC (both 4-byte encodings)
@@ -202,6 +209,73 @@ __device__ __forceinline__ int below_mask(const unsigned (&m)[4], int x)
     return c;
 }
 
+// sort + column gather + elimination + bookkeeping of one frame (one wavefront); results in registers
+__device__ __forceinline__ FrontResult front_device(FrontLds &L, const float *__restrict__ y, long long src,
+                                                    const u64 *__restrict__ Gcols, int lane)
+{
+    // ---- reliability sort: rank of each |y| in descending order, ties -> lower index ------
+    const int a1 = __float_as_int(y[src * 128 + lane]) & 0x7FFFFFFF;
+    const int a2 = __float_as_int(y[src * 128 + 64 + lane]) & 0x7FFFFFFF;
+    L.abits[lane] = a1;
+    L.abits[lane + 64] = a2;
+    wave_fence();
+    // rank = number of keys that sort before mine.  Fast path: strict integer compares only
+    // (v_cmp + v_addc through VCC, 2 instructions per key and element); equal keys then collide
+    // on a rank, which the read-back below detects, and only such frames (exact float ties,
+    // ~5e-4 of random frames) redo the count with the full "lower index first" rule.
+    int r1 = 0, r2 = 0;
+#pragma unroll 8
+    for (int u4 = 0; u4 < 32; ++u4) {
+        const int4 kq = *reinterpret_cast<const int4 *>(&L.abits[u4 * 4]);
+        rank_gt(r1, a1, kq.x); rank_gt(r2, a2, kq.x);
+        rank_gt(r1, a1, kq.y); rank_gt(r2, a2, kq.y);
+        rank_gt(r1, a1, kq.z); rank_gt(r2, a2, kq.z);
+        rank_gt(r1, a1, kq.w); rank_gt(r2, a2, kq.w);
+    }
+    L.pi1[r1] = (unsigned char)lane;
+    L.pi1[r2] = (unsigned char)(lane + 64);
+    wave_fence();
+    if (__ballot(L.pi1[r1] != lane || L.pi1[r2] != lane + 64)) {
+        wave_fence();
+        r1 = 0; r2 = 0;
+        // "u before v"  <=>  a_u > a_v  or  (a_u == a_v and u < v)
+        for (int u = 0; u < 128; ++u) {
+            const int ku = L.abits[u];
+            r1 += (ku > a1) || (ku == a1 && u < lane);
+            r2 += (ku > a2) || (ku == a2 && u < lane + 64);
+        }
+    }
+    wave_fence();
+    L.pi1[r1] = (unsigned char)lane;
+    L.pi1[r2] = (unsigned char)(lane + 64);
+    if (lane < 4) L.mask[lane] = 0;
+    wave_fence();
+    // ---- G with columns in sorted order, column-major ------------------------------------
+    u64 C1 = Gcols[L.pi1[lane]];
+    u64 C2 = Gcols[L.pi1[lane + 64]];
+    int rho = lane, idx1 = lane, idx2 = lane + 64;
+    const int ns = ge_columns(C1, C2, rho, idx1, idx2, lane, nullptr);
+    // ---- identify_mrb bookkeeping (pb_testing.py:276-304) --------------------------------
+    atomicOr(&L.mask[idx1 >> 5], 1u << (idx1 & 31));
+    wave_fence();
+    const unsigned m[4] = {L.mask[0], L.mask[1], L.mask[2], L.mask[3]};
+    const int rankM = below_mask(m, idx1);         // new MRB position of slot `lane`
+    const int rankL = idx2 - below_mask(m, idx2);  // new parity column of slot `lane`
+    L.perm[rankM] = L.pi1[idx1];
+    L.perm[64 + rankL] = L.pi1[idx2];
+    L.colbuf[rankL] = C2;
+    L.rowsrc[rankM] = (unsigned char)rho;          // pivot of MRB slot `lane` is physical row rho
+    wave_fence();
+    const u64 R = transpose64(L.colbuf[lane], lane);   // lane = physical row, bit = parity column
+    FrontResult res;
+    res.Prow = shfl64(R, L.rowsrc[lane]);
+    res.o1 = L.perm[lane];
+    res.o2 = L.perm[64 + lane];
+    res.ns = ns;
+    wave_fence();
+    return res;
+}
+
 __global__ __launch_bounds__(256) void osd_front_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                         const int *__restrict__ count, long long F,
                                                         const u64 *__restrict__ Gcols,
@@ -217,63 +291,11 @@ __global__ __launch_bounds__(256) void osd_front_kernel(const float *__restrict_
 
     for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
         const long long src = index ? index[f] : f;
-        // ---- reliability sort: rank of each |y| in descending order, ties -> lower index ------
-        const int a1 = __float_as_int(y[src * 128 + lane]) & 0x7FFFFFFF;
-        const int a2 = __float_as_int(y[src * 128 + 64 + lane]) & 0x7FFFFFFF;
-        L.abits[lane] = a1;
-        L.abits[lane + 64] = a2;
-        wave_fence();
-        // rank = number of keys that sort before mine.  Fast path: strict integer compares only
-        // (v_cmp + v_addc through VCC, 2 instructions per key and element); equal keys then collide
-        // on a rank, which the read-back below detects, and only such frames (exact float ties,
-        // ~5e-4 of random frames) redo the count with the full "lower index first" rule.
-        int r1 = 0, r2 = 0;
-#pragma unroll 8
-        for (int u4 = 0; u4 < 32; ++u4) {
-            const int4 kq = *reinterpret_cast<const int4 *>(&L.abits[u4 * 4]);
-            rank_gt(r1, a1, kq.x); rank_gt(r2, a2, kq.x);
-            rank_gt(r1, a1, kq.y); rank_gt(r2, a2, kq.y);
-            rank_gt(r1, a1, kq.z); rank_gt(r2, a2, kq.z);
-            rank_gt(r1, a1, kq.w); rank_gt(r2, a2, kq.w);
-        }
-        L.pi1[r1] = (unsigned char)lane;
-        L.pi1[r2] = (unsigned char)(lane + 64);
-        wave_fence();
-        if (__ballot(L.pi1[r1] != lane || L.pi1[r2] != lane + 64)) {
-            wave_fence();
-            r1 = 0; r2 = 0;
-            // "u before v"  <=>  a_u > a_v  or  (a_u == a_v and u < v)
-            for (int u = 0; u < 128; ++u) {
-                const int ku = L.abits[u];
-                r1 += (ku > a1) || (ku == a1 && u < lane);
-                r2 += (ku > a2) || (ku == a2 && u < lane + 64);
-            }
-        }
-        wave_fence();
-        L.pi1[r1] = (unsigned char)lane;
-        L.pi1[r2] = (unsigned char)(lane + 64);
-        if (lane < 4) L.mask[lane] = 0;
-        wave_fence();
-        // ---- G with columns in sorted order, column-major ------------------------------------
-        u64 C1 = Gcols[L.pi1[lane]];
-        u64 C2 = Gcols[L.pi1[lane + 64]];
-        int rho = lane, idx1 = lane, idx2 = lane + 64;
-        const int ns = ge_columns(C1, C2, rho, idx1, idx2, lane, nullptr);
-        // ---- identify_mrb bookkeeping (pb_testing.py:276-304) --------------------------------
-        atomicOr(&L.mask[idx1 >> 5], 1u << (idx1 & 31));
-        wave_fence();
-        const unsigned m[4] = {L.mask[0], L.mask[1], L.mask[2], L.mask[3]};
-        const int rankM = below_mask(m, idx1);         // new MRB position of slot `lane`
-        const int rankL = idx2 - below_mask(m, idx2);  // new parity column of slot `lane`
-        perm_out[f * 128 + rankM] = L.pi1[idx1];
-        perm_out[f * 128 + 64 + rankL] = L.pi1[idx2];
-        L.colbuf[rankL] = C2;
-        L.rowsrc[rankM] = (unsigned char)rho;          // pivot of MRB slot `lane` is physical row rho
-        wave_fence();
-        const u64 R = transpose64(L.colbuf[lane], lane);   // lane = physical row, bit = parity column
-        parity_out[f * 64 + lane] = shfl64(R, L.rowsrc[lane]);
-        if (nswaps && lane == 0) nswaps[f] = ns;
-        wave_fence();
+        const FrontResult res = front_device(L, y, src, Gcols, lane);
+        perm_out[f * 128 + lane] = (unsigned char)res.o1;
+        perm_out[f * 128 + 64 + lane] = (unsigned char)res.o2;
+        parity_out[f * 64 + lane] = res.Prow;
+        if (nswaps && lane == 0) nswaps[f] = res.ns;
     }
 }
 
@@ -303,15 +325,13 @@ struct SearchFrame {
     int o1, o2;       // original bit index of primed positions lane and 64 + lane
 };
 
-__device__ __forceinline__ SearchFrame search_prepare(SearchLds &L, const float *__restrict__ y, long long src,
-                                                      const unsigned char *__restrict__ perm_in,
-                                                      const u64 *__restrict__ parity_in, long long f, int lane)
+__device__ __forceinline__ SearchFrame search_prepare_regs(SearchLds &L, const float *__restrict__ y, long long src,
+                                                           int o1, int o2, u64 Prow, int lane)
 {
     SearchFrame S;
-    S.o1 = perm_in[f * 128 + lane];
-    S.o2 = perm_in[f * 128 + 64 + lane];
+    S.o1 = o1;
+    S.o2 = o2;
     const float y1 = y[src * 128 + S.o1], y2 = y[src * 128 + S.o2];   // y'[p] = y[perm[p]]
-    const u64 Prow = parity_in[f * 64 + lane];
     L.perm[lane] = (unsigned char)S.o1;
     L.perm[lane + 64] = (unsigned char)S.o2;
     L.w[lane] = __builtin_fabsf(y1);
@@ -353,6 +373,13 @@ __device__ __forceinline__ SearchFrame search_prepare(SearchLds &L, const float 
     S.d0 = sel ^ S.hp;
     wave_fence();
     return S;
+}
+
+__device__ __forceinline__ SearchFrame search_prepare(SearchLds &L, const float *__restrict__ y, long long src,
+                                                      const unsigned char *__restrict__ perm_in,
+                                                      const u64 *__restrict__ parity_in, long long f, int lane)
+{
+    return search_prepare_regs(L, y, src, perm_in[f * 128 + lane], perm_in[f * 128 + 64 + lane], parity_in[f * 64 + lane], lane);
 }
 
 // candidate (E = flipped MRB positions, D = parity discrepancy) -> codeword in ORIGINAL bit order
@@ -446,6 +473,56 @@ __device__ __forceinline__ int tep2_rank(int bi, int bj, const int *__restrict__
     return 65 + base2[s] + bi - (s > 63 ? s - 63 : 0);
 }
 
+// the order-0/1/2 scan of one prepared frame; returns the winner (metric, table rank, D, E) in every lane
+template <bool PRUNE>
+__device__ __forceinline__ void search2_device(SearchLds &L, const SearchFrame &S, const int *__restrict__ base2, int lane,
+                                               float &best_out, int &rank_out, u64 &D_out, u64 &E_out)
+{
+    const u64 Pl = L.P[lane], Pm = L.P[63 - lane];
+    const float wl = L.w[lane], wm = L.w[63 - lane];
+    // order 0 (rank 0, identical in every lane), then order 1: lane l owns TEP {l}
+    float best = tep_cost(L, 0.0f, S.d0);
+    int bi = -1, bj = -1;
+    u64 bestD = S.d0;
+    {
+        const u64 D = S.d0 ^ Pl;
+        const float c = tep_cost(L, wl, D);
+        if (c < best) { best = c; bj = lane; bestD = D; }      // a tie keeps the lower rank (order 0)
+    }
+    // exact pruning: a TEP whose flipped-MRB weight alone exceeds the best metric found so far by
+    // ANY lane can neither win nor tie (the parity terms only add), so its LUT reads are skipped;
+    // masked-off lanes also stay out of the LDS bank arbitration.  bestU is refreshed every 8 rounds.
+    float bestU = best;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bestU = __builtin_fminf(bestU, __shfl(bestU, lane ^ off, 64));
+    for (int r = 0; r < 32; ++r) {
+        const u64 Pr = readlane64(Pl, r), Pq = readlane64(Pl, 62 - r);
+        const float wr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), r));
+        const float wq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), 62 - r));
+        const bool up = lane > r;
+        const bool active = up || r < 31;        // at r = 31 the lower half would repeat i = 31
+        const float M = up ? (wr + wl) : (wq + wm);            // |y'_i| + |y'_j|, i < j
+        if (active && (!PRUNE || !(M > bestU))) {
+            const u64 D = S.d0 ^ (up ? (Pr ^ Pl) : (Pq ^ Pm));
+            const float c = tep_cost(L, M, D);
+            const int ci = up ? r : 62 - r, cj = up ? lane : 63 - lane;
+            // equal metrics are ordered by table rank (practically never taken)
+            if (c < best || (c == best && tep2_rank(ci, cj, base2) < tep2_rank(bi, bj, base2))) {
+                best = c; bi = ci; bj = cj; bestD = D;
+            }
+        }
+        if (PRUNE && (r & 7) == 7) {
+            bestU = __builtin_fminf(bestU, best);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) bestU = __builtin_fminf(bestU, __shfl(bestU, lane ^ off, 64));
+        }
+    }
+    int bestt = tep2_rank(bi, bj, base2);
+    u64 bestE = (bi >= 0 ? 1ull << bi : 0ull) | (bj >= 0 ? 1ull << bj : 0ull);
+    wave_argmin(best, bestt, bestD, bestE, lane);
+    best_out = best; rank_out = bestt; D_out = bestD; E_out = bestE;
+}
+
 template <bool PRUNE>
 __global__ __launch_bounds__(256) void osd_search2_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                           const int *__restrict__ count, long long F,
@@ -465,49 +542,55 @@ __global__ __launch_bounds__(256) void osd_search2_kernel(const float *__restric
     for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
         const long long src = index ? index[f] : f;
         const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
-        const u64 Pl = L.P[lane], Pm = L.P[63 - lane];
-        const float wl = L.w[lane], wm = L.w[63 - lane];
-        // order 0 (rank 0, identical in every lane), then order 1: lane l owns TEP {l}
-        float best = tep_cost(L, 0.0f, S.d0);
-        int bi = -1, bj = -1;
-        u64 bestD = S.d0;
-        {
-            const u64 D = S.d0 ^ Pl;
-            const float c = tep_cost(L, wl, D);
-            if (c < best) { best = c; bj = lane; bestD = D; }      // a tie keeps the lower rank (order 0)
-        }
-        // exact pruning: a TEP whose flipped-MRB weight alone exceeds the best metric found so far by
-        // ANY lane can neither win nor tie (the parity terms only add), so its LUT reads are skipped;
-        // masked-off lanes also stay out of the LDS bank arbitration.  bestU is refreshed every 8 rounds.
-        float bestU = best;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) bestU = __builtin_fminf(bestU, __shfl(bestU, lane ^ off, 64));
-        for (int r = 0; r < 32; ++r) {
-            const u64 Pr = readlane64(Pl, r), Pq = readlane64(Pl, 62 - r);
-            const float wr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), r));
-            const float wq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), 62 - r));
-            const bool up = lane > r;
-            const bool active = up || r < 31;        // at r = 31 the lower half would repeat i = 31
-            const float M = up ? (wr + wl) : (wq + wm);            // |y'_i| + |y'_j|, i < j
-            if (active && (!PRUNE || !(M > bestU))) {
-                const u64 D = S.d0 ^ (up ? (Pr ^ Pl) : (Pq ^ Pm));
-                const float c = tep_cost(L, M, D);
-                const int ci = up ? r : 62 - r, cj = up ? lane : 63 - lane;
-                // equal metrics are ordered by table rank (practically never taken)
-                if (c < best || (c == best && tep2_rank(ci, cj, base2) < tep2_rank(bi, bj, base2))) {
-                    best = c; bi = ci; bj = cj; bestD = D;
-                }
-            }
-            if (PRUNE && (r & 7) == 7) {
-                bestU = __builtin_fminf(bestU, best);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) bestU = __builtin_fminf(bestU, __shfl(bestU, lane ^ off, 64));
-            }
-        }
-        int bestt = tep2_rank(bi, bj, base2);
-        u64 bestE = (bi >= 0 ? 1ull << bi : 0ull) | (bj >= 0 ? 1ull << bj : 0ull);
-        wave_argmin(best, bestt, bestD, bestE, lane);
+        float best; int bestt; u64 bestD, bestE;
+        search2_device<PRUNE>(L, S, base2, lane, best, bestt, bestD, bestE);
         search_finish(L, S, bestE, bestD, f, lane, cw_out);
+        if (lane == 0) {
+            if (metric_out) metric_out[f] = best;
+            if (best_out) best_out[f] = bestt;
+            if (ntep_out) ntep_out[f] = 2081;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused conventional OSD-2: front end + order-2 scan of a frame in ONE kernel, results handed over in
+// registers / LDS (no workspace round trip).  Besides saving a launch, fusing lets the two phases of
+// DIFFERENT frames share a CU at the same time: the front end is VALU/latency bound, the scan LDS
+// bound, so co-resident waves in different phases overlap where two back-to-back kernels cannot.
+// The LDS of a wave is one buffer viewed as FrontLds during the front end and SearchLds afterwards.
+// ---------------------------------------------------------------------------------------
+constexpr size_t kFusedLds = sizeof(SearchLds) > sizeof(FrontLds) ? sizeof(SearchLds) : sizeof(FrontLds);
+
+__global__ __launch_bounds__(256) void osd_decode2_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                          const int *__restrict__ count, long long F,
+                                                          const u64 *__restrict__ Gcols, const int *__restrict__ base2,
+                                                          unsigned char *__restrict__ perm_out /*nullable*/,
+                                                          u64 *__restrict__ parity_out /*nullable*/,
+                                                          u64 *__restrict__ cw_out, float *__restrict__ metric_out,
+                                                          int *__restrict__ best_out, int *__restrict__ ntep_out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char raw[4][kFusedLds];
+    const int lane = threadIdx.x & 63;
+    FrontLds &LF = *reinterpret_cast<FrontLds *>(raw[threadIdx.x >> 6]);
+    SearchLds &LS = *reinterpret_cast<SearchLds *>(raw[threadIdx.x >> 6]);
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+
+    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+        const long long src = index ? index[f] : f;
+        const FrontResult fr = front_device(LF, y, src, Gcols, lane);
+        if (perm_out) {
+            perm_out[f * 128 + lane] = (unsigned char)fr.o1;
+            perm_out[f * 128 + 64 + lane] = (unsigned char)fr.o2;
+        }
+        if (parity_out) parity_out[f * 64 + lane] = fr.Prow;
+        wave_fence();
+        const SearchFrame S = search_prepare_regs(LS, y, src, fr.o1, fr.o2, fr.Prow, lane);
+        float best; int bestt; u64 bestD, bestE;
+        search2_device<false>(LS, S, base2, lane, best, bestt, bestD, bestE);
+        search_finish(LS, S, bestE, bestD, f, lane, cw_out);
         if (lane == 0) {
             if (metric_out) metric_out[f] = best;
             if (best_out) best_out[f] = bestt;
@@ -1100,6 +1183,13 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
         if (rc) return rc;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (p->algo == LDPC_OSD_CONVENTIONAL && p->order == 2 && !p->reserved) {   // fused front end + order-2 scan
+        hipLaunchKernelGGL(osd_decode2_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
+                           reinterpret_cast<const u64 *>(ctx->d_Gcols), st->d_base2, (unsigned char *)nullptr, (u64 *)nullptr,
+                           reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
+        LDPC_HIP(hipGetLastError());
+        return LDPC_OK;
+    }
     hipLaunchKernelGGL(osd_front_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
                        reinterpret_cast<const u64 *>(ctx->d_Gcols), st->d_perm, st->d_parity, (int *)nullptr);
     return launch_search(ctx, d_y, d_index, d_count, F, st->d_perm, st->d_parity, p, d_cw, d_metric, d_best, d_ntep, s);

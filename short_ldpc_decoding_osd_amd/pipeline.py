@@ -17,7 +17,7 @@ from .runtime import Decoder
 
 class BatchPipeline:
     def __init__(self, dec: Decoder, B: int, T: int, alpha, osd_order=None, osd_algo=_lib.OSD_CONVENTIONAL, snr_db=0.0,
-                 w_in=1.0, w_out=1.0, want_soft=True, **osd_kw):
+                 w_in=1.0, w_out=1.0, want_soft=True, keep_front=False, **osd_kw):
         self.dec, self.B, self.T = dec, int(B), int(T)
         e = dec.empty
         self.soft = e((B, dec.n), torch.float32) if want_soft else None
@@ -37,13 +37,17 @@ class BatchPipeline:
         self.osd_order = osd_order
         if osd_order is not None:
             self.index, self.count = e((B,), torch.int32), e((1,), torch.int32)
-            self.perm, self.parity = e((B, 128), torch.uint8), e((B, 64), torch.int64)
+            # keep_front: also return the front-end results (two kernels); otherwise ldpc_osd_decode picks the
+            # fused kernel where one exists (conventional OSD-2)
+            self.perm = e((B, 128), torch.uint8) if keep_front else None
+            self.parity = e((B, 64), torch.int64) if keep_front else None
             self.cw, self.metric = e((B, 2), torch.int64), e((B,), torch.float32)
             self.best, self.ntep = e((B,), torch.int32), e((B,), torch.int32)
             self.aux = torch.zeros((B, 4), dtype=torch.int32, device=dec.device) if osd_algo == _lib.OSD_PB else None
             p.osd = dec.osd_params(osd_order, osd_algo, snr_db=snr_db, aux=self.aux, **osd_kw)
             p.d_index, p.d_count = self.index.data_ptr(), self.count.data_ptr()
-            p.d_perm, p.d_parity = self.perm.data_ptr(), self.parity.data_ptr()
+            p.d_perm = self.perm.data_ptr() if keep_front else None
+            p.d_parity = self.parity.data_ptr() if keep_front else None
             p.d_cw, p.d_metric = self.cw.data_ptr(), self.metric.data_ptr()
             p.d_best, p.d_ntep = self.best.data_ptr(), self.ntep.data_ptr()
             p.d_osd_counts = self.osd_counts.data_ptr()
