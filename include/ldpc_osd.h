@@ -233,7 +233,7 @@ typedef struct ldpc_pipeline {
     ldpc_osd_params osd;
     int32_t *d_index, *d_count;    /* [B], [1]                                             */
     uint8_t *d_perm;               /* [B][128] nullable: both NULL = ldpc_osd_decode on the     */
-    uint64_t *d_parity;            /* [B][64]  context workspace (fused kernel for OSD-2)       */
+    uint64_t *d_parity;            /* [B][64]  context workspace (no per-kernel OSD timing)     */
     uint64_t *d_cw;                /* [B][2]                                               */
     float *d_metric;               /* [B] nullable                                         */
     int32_t *d_best, *d_ntep;      /* [B] nullable / [B]                                   */

@@ -123,7 +123,7 @@ int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
             if (ev) LDPC_HIP(hipEventRecord(ev[3], s));
             if ((rc = ldpc_osd_search(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, &p->osd, p->d_cw,
                                       p->d_metric, p->d_best, p->d_ntep, stream))) return rc;
-        } else {                          // ldpc_osd_decode: fused kernel where one exists (conventional order 2)
+        } else {                          // ldpc_osd_decode on the context's workspace
             if (ev) LDPC_HIP(hipEventRecord(ev[3], s));
             if ((rc = ldpc_osd_decode(ctx, p->d_llr, p->d_index, p->d_count, p->B, &p->osd, p->d_cw, p->d_metric, p->d_best,
                                       p->d_ntep, stream))) return rc;

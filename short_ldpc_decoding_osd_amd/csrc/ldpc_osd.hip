@@ -554,52 +554,6 @@ __global__ __launch_bounds__(256) void osd_search2_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------
-// Fused conventional OSD-2: front end + order-2 scan of a frame in ONE kernel, results handed over in
-// registers / LDS (no workspace round trip).  Besides saving a launch, fusing lets the two phases of
-// DIFFERENT frames share a CU at the same time: the front end is VALU/latency bound, the scan LDS
-// bound, so co-resident waves in different phases overlap where two back-to-back kernels cannot.
-// The LDS of a wave is one buffer viewed as FrontLds during the front end and SearchLds afterwards.
-// ---------------------------------------------------------------------------------------
-constexpr size_t kFusedLds = sizeof(SearchLds) > sizeof(FrontLds) ? sizeof(SearchLds) : sizeof(FrontLds);
-
-__global__ __launch_bounds__(256) void osd_decode2_kernel(const float *__restrict__ y, const int *__restrict__ index,
-                                                          const int *__restrict__ count, long long F,
-                                                          const u64 *__restrict__ Gcols, const int *__restrict__ base2,
-                                                          unsigned char *__restrict__ perm_out /*nullable*/,
-                                                          u64 *__restrict__ parity_out /*nullable*/,
-                                                          u64 *__restrict__ cw_out, float *__restrict__ metric_out,
-                                                          int *__restrict__ best_out, int *__restrict__ ntep_out)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char raw[4][kFusedLds];
-    const int lane = threadIdx.x & 63;
-    FrontLds &LF = *reinterpret_cast<FrontLds *>(raw[threadIdx.x >> 6]);
-    SearchLds &LS = *reinterpret_cast<SearchLds *>(raw[threadIdx.x >> 6]);
-    long long nframes = F;
-    if (count) { const long long c = *count; nframes = c < F ? c : F; }
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-
-    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
-        const long long src = index ? index[f] : f;
-        const FrontResult fr = front_device(LF, y, src, Gcols, lane);
-        if (perm_out) {
-            perm_out[f * 128 + lane] = (unsigned char)fr.o1;
-            perm_out[f * 128 + 64 + lane] = (unsigned char)fr.o2;
-        }
-        if (parity_out) parity_out[f * 64 + lane] = fr.Prow;
-        wave_fence();
-        const SearchFrame S = search_prepare_regs(LS, y, src, fr.o1, fr.o2, fr.Prow, lane);
-        float best; int bestt; u64 bestD, bestE;
-        search2_device<false>(LS, S, base2, lane, best, bestt, bestD, bestE);
-        search_finish(LS, S, bestE, bestD, f, lane, cw_out);
-        if (lane == 0) {
-            if (metric_out) metric_out[f] = best;
-            if (best_out) best_out[f] = bestt;
-            if (ntep_out) ntep_out[f] = 2081;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // FS-OSD (fs_osd, FS_OSD/fs_testing.py:129-161): order-by-order scan in the order of
 // generate_sequential_teps (:32-49) with two Hamming-distance rules (one_tep_compare :51-64):
 //   HD < tau_e            -> stop everything (the candidate is appended to optimal_list, :143-146)
@@ -1183,13 +1137,6 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
         if (rc) return rc;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (p->algo == LDPC_OSD_CONVENTIONAL && p->order == 2 && !p->reserved) {   // fused front end + order-2 scan
-        hipLaunchKernelGGL(osd_decode2_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
-                           reinterpret_cast<const u64 *>(ctx->d_Gcols), st->d_base2, (unsigned char *)nullptr, (u64 *)nullptr,
-                           reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
-        LDPC_HIP(hipGetLastError());
-        return LDPC_OK;
-    }
     hipLaunchKernelGGL(osd_front_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
                        reinterpret_cast<const u64 *>(ctx->d_Gcols), st->d_perm, st->d_parity, (int *)nullptr);
     return launch_search(ctx, d_y, d_index, d_count, F, st->d_perm, st->d_parity, p, d_cw, d_metric, d_best, d_ntep, s);

@@ -17,7 +17,7 @@ from .runtime import Decoder
 
 class BatchPipeline:
     def __init__(self, dec: Decoder, B: int, T: int, alpha, osd_order=None, osd_algo=_lib.OSD_CONVENTIONAL, snr_db=0.0,
-                 w_in=1.0, w_out=1.0, want_soft=True, keep_front=False, **osd_kw):
+                 w_in=1.0, w_out=1.0, want_soft=True, keep_front=True, **osd_kw):
         self.dec, self.B, self.T = dec, int(B), int(T)
         e = dec.empty
         self.soft = e((B, dec.n), torch.float32) if want_soft else None
@@ -37,8 +37,8 @@ class BatchPipeline:
         self.osd_order = osd_order
         if osd_order is not None:
             self.index, self.count = e((B,), torch.int32), e((1,), torch.int32)
-            # keep_front: also return the front-end results (two kernels); otherwise ldpc_osd_decode picks the
-            # fused kernel where one exists (conventional OSD-2)
+            # keep_front: the front-end results (perm, P' rows) land in buffers of this object and the two
+            # OSD kernels are timed separately; otherwise they go through the context's workspace
             self.perm = e((B, 128), torch.uint8) if keep_front else None
             self.parity = e((B, 64), torch.int64) if keep_front else None
             self.cw, self.metric = e((B, 2), torch.int64), e((B,), torch.float32)

@@ -202,21 +202,20 @@ def test_single_call_pipeline_equals_the_separate_calls(dec):
     rng = np.random.default_rng(71)
     y, cw = np_oracle.make_frames(dec.code.G, 2.5, 5000, rng)
     yd, lab = to_dev(y, dec), dec.pack_bits(to_dev(cw, dec))
-    pipe = BatchPipeline(dec, 5000, 10, ALPHA0, osd_order=2).bind(yd, lab)            # fused OSD-2 kernel
+    pipe = BatchPipeline(dec, 5000, 10, ALPHA0, osd_order=2).bind(yd, lab)                       # own front-end buffers
     pipe.run(timing_slot=3)
     pipe.run()
-    pipe2k = BatchPipeline(dec, 5000, 10, ALPHA0, osd_order=2, keep_front=True).bind(yd, lab)   # front + search kernels
-    pipe2k.run(timing_slot=4)
+    pipe_ws = BatchPipeline(dec, 5000, 10, ALPHA0, osd_order=2, keep_front=False).bind(yd, lab)   # context workspace
+    pipe_ws.run(timing_slot=4)
     torch.cuda.synchronize()
-    for k in ("cw", "metric", "best", "ntep", "index", "count"):
-        assert torch.equal(getattr(pipe, k), getattr(pipe2k, k)) or k in ("cw", "metric", "best", "ntep"), k
     nf0 = int(pipe.count.cpu()[0])
+    assert int(pipe_ws.count.cpu()[0]) == nf0 and torch.equal(pipe.index[:nf0], pipe_ws.index[:nf0])
     for k in ("cw", "metric", "best", "ntep"):
-        assert torch.equal(getattr(pipe, k)[:nf0], getattr(pipe2k, k)[:nf0]), k
-    perm_o, par_o, _ = dec.osd_front(yd, index=pipe2k.index, count=pipe2k.count, F=5000)
+        assert torch.equal(getattr(pipe, k)[:nf0], getattr(pipe_ws, k)[:nf0]), k
+    perm_o, par_o, _ = dec.osd_front(yd, index=pipe.index, count=pipe.count, F=5000)
     torch.cuda.synchronize()
-    assert torch.equal(pipe2k.perm[:nf0], perm_o[:nf0]) and torch.equal(pipe2k.parity[:nf0], par_o[:nf0])
-    assert pipe2k.timing(4)[1] > 0 and pipe.timing(3)[1] == 0
+    assert torch.equal(pipe.perm[:nf0], perm_o[:nf0]) and torch.equal(pipe.parity[:nf0], par_o[:nf0])
+    assert pipe.timing(3)[1] > 2 * pipe_ws.timing(4)[1]        # workspace path: no separate front-end interval
     res = dec.nms(yd, 10, ALPHA0)
     index, count = dec.compact(res["fail"])
     nf = int(count.cpu()[0])
