@@ -42,7 +42,12 @@ WORKLOADS = {
     "nms10": (None, 65536, "configs[1]: NMS-10, 65 536 frames, 1 GPU"),
     "nms10_osd0": (0, 65536, "configs[2]: NMS-10 + OSD-0, 65 536 frames"),
     "nms10_osd2": (2, 131072, "configs[3]: NMS-10 + OSD-2, 2^20 frames over 8 GPUs = 131 072 per GPU"),
+    # not headline lines: the other two searches at 2.5 dB, for kernel timing (configs[4] sweeps them over SNR,
+    # scripts/snr_sweep.py)
+    "nms10_fs2": (2, 131072, "NMS-10 + FS-OSD order 2 (beta 0.1, tau_e 6.5, tau_psc 30)"),
+    "nms10_pb3": (3, 131072, "NMS-10 + PB-OSD order 3 (configs[4] at one SNR point)"),
 }
+OSD_ALGO = {"nms10_fs2": 1, "nms10_pb3": 2}
 
 
 def make_frames(dec, B, seed):
@@ -145,11 +150,12 @@ def main():
     y, labels = make_frames(dec, B, seed=20241020 + rank)
     from short_ldpc_decoding_osd_amd._lib import TIMING_SLOTS
     from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline
-    step = BatchPipeline(dec, B, T_ITERS, ALPHA, osd_order=order).bind(y, labels)
+    algo = OSD_ALGO.get(args.workload, 0)
+    step = BatchPipeline(dec, B, T_ITERS, ALPHA, osd_order=order, osd_algo=algo, snr_db=SNR_DB).bind(y, labels)
     lanes = [(torch.cuda.current_stream(), step)]
     for extra in range(1, max(1, args.streams)):      # every extra stream decodes its own batch
         y2, lab2 = make_frames(dec, B, seed=20241020 + rank + 1000 * extra)
-        lanes.append((torch.cuda.Stream(), BatchPipeline(dec, B, T_ITERS, ALPHA, osd_order=order).bind(y2, lab2)))
+        lanes.append((torch.cuda.Stream(), BatchPipeline(dec, B, T_ITERS, ALPHA, osd_order=order, osd_algo=algo, snr_db=SNR_DB).bind(y2, lab2)))
 
     def run_step(k, slot=-1):
         st, pipe = lanes[k % len(lanes)]
@@ -216,7 +222,8 @@ def main():
             f_per_step = c[5] / (args.steps * world)
             if tm[:, 1].mean() > 0.02:   # two-kernel OSD (front end + search through the workspace)
                 kern["osd_front_kernel"] = (float(tm[:, 1].mean()), (512 + 640) * f_per_step)
-                kern["osd_search2_kernel" if order == 2 else "osd_search_kernel"] = (float(tm[:, 2].mean()), (1152 + 24) * f_per_step)
+                sname = {1: "osd_fs_kernel", 2: "osd_pb_kernel"}.get(algo, "osd_search2_kernel" if order == 2 else "osd_search_kernel")
+                kern[sname] = (float(tm[:, 2].mean()), (1152 + 24) * f_per_step)
             else:                        # OSD through the context workspace: one combined duration
                 kern["osd_front+search"] = (float(tm[:, 2].mean()), OSD_BYTES_PER_FRAME * f_per_step)
         name = max(kern, key=lambda k: kern[k][0])

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: SNR sweep of (learned-)NMS + PB-OSD (or FS / conventional OSD) with frames sharded
+across the GPUs of a node and ONE RCCL all-reduce of the counters per SNR point.
+
+    python scripts/snr_sweep.py --snr 1.0 3.5 6 --frames 1048576 --osd pb --order 3
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/snr_sweep.py ...
+
+Prints one JSON line per SNR point (rank 0): FER_NMS, FER_OSD|fail, their product (what the reference's
+recipe multiplies by hand, `Training and Testing recipe.txt:18`), end-to-end FER, mean TEPs, frames/s.
+The reference sweeps 2.0-3.0 dB with order 3 and stops each point at 100 OSD failures
+(PB_OSD/globalmap.py:42-43); here every point decodes the requested number of frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from short_ldpc_decoding_osd_amd import Code, _lib  # noqa: E402
+from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline  # noqa: E402
+from short_ldpc_decoding_osd_amd.runtime import Decoder  # noqa: E402
+from short_ldpc_decoding_osd_amd.sharding import allreduce_counters, combine_fer, rank_seed, shard_range  # noqa: E402
+
+ALGOS = {"conv": _lib.OSD_CONVENTIONAL, "fs": _lib.OSD_FS, "pb": _lib.OSD_PB}
+
+
+def frames_on_device(dec, B, snr_db, gen):
+    G = torch.from_numpy(dec.code.G).to(device=dec.device, dtype=torch.float32)
+    sigma = float(np.sqrt(1.0 / (2.0 * (dec.k / dec.n) * 10.0 ** (snr_db / 10.0))))
+    cw = (torch.randint(0, 2, (B, dec.k), device=dec.device, generator=gen).to(torch.float32) @ G).remainder_(2)
+    y = ((1 - 2 * cw) * (1 + sigma * torch.randn((B, dec.n), device=dec.device, generator=gen))).contiguous()
+    return y, dec.pack_bits(cw.to(torch.uint8))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--snr", nargs=3, default=["1.0", "3.5", "6"], metavar=("LO", "HI", "NUM"))
+    ap.add_argument("--frames", type=int, default=1 << 20, help="frames per SNR point, all ranks together")
+    ap.add_argument("--batch", type=int, default=131072, help="frames per device batch")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--osd", choices=sorted(ALGOS), default="pb")
+    ap.add_argument("--order", type=int, default=3)
+    ap.add_argument("--weight", type=float, default=-0.048, help="stored (pre-softplus) NMS-1 weight")
+    ap.add_argument("--values", default=None, help="par/values.txt of the training stage (overrides --weight)")
+    args = ap.parse_args()
+
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    stored = args.weight
+    if args.values:
+        from short_ldpc_decoding_osd_amd import weights
+        _, v = weights.parse_values_txt(args.values)
+        stored = float([x for k, x in v.items() if "check" in k][0][0])
+    alpha = float(np.log1p(np.exp(stored)))                     # softplus, ms_test.py:207-208
+    dec = Decoder(Code(), local)
+    lo, hi = shard_range(args.frames, rank, world)
+    mine = hi - lo
+    gen = torch.Generator(device=dec.device).manual_seed(rank_seed(20241020, rank))
+    for snr in np.linspace(float(args.snr[0]), float(args.snr[1]), int(args.snr[2])):
+        snr = round(float(snr), 2)
+        total = torch.zeros(8, dtype=torch.int64, device=dec.device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done = 0
+        while done < mine:
+            B = min(args.batch, mine - done)
+            y, lab = frames_on_device(dec, B, snr, gen)
+            pipe = BatchPipeline(dec, B, args.iters, alpha, osd_order=args.order, osd_algo=ALGOS[args.osd], snr_db=snr,
+                                 want_soft=False, keep_front=False).bind(y, lab)
+            pipe.run()
+            total += pipe.counters()
+            done += B
+        total = allreduce_counters(total)                       # the one exchange step per SNR point
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            out = combine_fer(total.cpu().numpy())
+            out.update(snr_db=snr, osd=args.osd, order=args.order, alpha=alpha, n_gpus=world,
+                       frames_per_s_incl_generation=args.frames / dt)
+            print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -377,6 +377,14 @@ int launch_nms(ldpc_ctx *ctx, const float *d_llr, int64_t B, int T, const float 
     } else if (kernel == LDPC_NMS_GENERIC) {
         const size_t lds = sizeof(float) * 4 * ((size_t)c.E + 2 * (size_t)c.n);
         if (lds > 160 * 1024) return fail(LDPC_E_UNSUPPORTED, "code too large for the generic NMS kernel (%zu B of LDS)", lds);
+        if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in (gfx950 has 160 KiB per CU)
+            static thread_local size_t granted = 0;
+            if (lds > granted) {
+                LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_generic_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                granted = lds;
+            }
+        }
         long long want = (B + 3) / 4;
         const unsigned blocks = (unsigned)(want < 8192 ? want : 8192);
         hipLaunchKernelGGL(nms_generic_kernel, dim3(blocks), dim3(256), lds, st, d_llr, (long long)B, T, a, w_in, w_out,

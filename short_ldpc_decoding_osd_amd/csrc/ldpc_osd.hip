@@ -670,7 +670,7 @@ struct PbEntry {
     unsigned seq;       // insertion number = position in the reference's growing list
     unsigned pos;       // pos0 | pos1 << 8 | pos2 << 16 | weight << 24  (ascending positions)
 };
-constexpr int kPbLdsEntries = 384;
+constexpr int kPbLdsEntries = 128;   // typical frontiers stay below this; the rest spills to global memory
 
 struct __attribute__((aligned(16))) PbLds {
     double cdfA[65];            // P[Bin(64, p1) <= b]
@@ -721,6 +721,7 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
         wave_fence();
         // sequential (ascending position) means / product, as the oracle defines them
         float a1 = 0.0f, aw = 0.0f, at = 0.0f, spl = 1.0f;
+#pragma unroll 4
         for (int p = 0; p < 64; ++p) {
             a1 = a1 + B.q[64 + p];
             aw = aw + L.w[64 + p];
@@ -736,6 +737,7 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
             const double ratio = (double)p1 / q;
             double acc = t;
             if (lane == 0) B.cdfA[0] = acc;
+#pragma unroll 2
             for (int i = 0; i < 64; ++i) {
                 t = t * coef[i] * ratio;
                 acc = acc + t;
@@ -835,6 +837,7 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
                 best = cost; bestD = D; bestE = E; bestidx = j + 1;
                 const float ratio = (1.0f - w1) / w1;
                 float prod = 1.0f;
+#pragma unroll 4
                 for (int p = 0; p < 64; ++p) {
                     const float qp = B.q[64 + p];
                     prod = prod * (((D >> p) & 1) ? 2.0f * qp : 2.0f * (1.0f - qp));

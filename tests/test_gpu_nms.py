@@ -96,7 +96,8 @@ def test_nms_empty_batch(dec):
 
 @pytest.mark.parametrize("name,alist", [
     ("array_121_60", "tests/golden/ArrayCode_N121_K60_r0.50.alist"),
-    ("ldpc_96_48", "tests/golden/LDPC_N96_K48_P8_set0_dmin10.alist")])
+    ("ldpc_96_48", "tests/golden/LDPC_N96_K48_P8_set0_dmin10.alist"),
+    ("wimax_1056", "tests/golden/wimax_1056_0.83.alist")])           # 80 KiB of LDS per block: opt-in path
 def test_generic_kernel_other_codes(name, alist):
     from short_ldpc_decoding_osd_amd import Code, _lib
     from short_ldpc_decoding_osd_amd.runtime import Decoder
