@@ -665,31 +665,52 @@ __device__ __forceinline__ float det_expf(float x)
     return e * __int_as_float(((int)kf + 127) << 23);
 }
 
+// Frontier = the reference's growing TEP list (optimal_tep_sequence :366-397) kept in INSERTION order:
+// a popped entry is tombstoned in place (sum = +inf), children are appended, so "first minimum in list
+// order" is the arg-min on (sum, slot).  A search that never stops visits all N_max TEPs with a list of
+// tens of thousands of entries, so the arg-min is kept hierarchical: cmin[c] = best (sum, slot) of the 64
+// slots of chunk c, smin[s] = best of the 64 chunks of super-chunk s.  A pop reads the <= 32 super-minima,
+// then re-reduces one chunk and one super-chunk: ~3 wave reductions per TEP whatever the list length.
+// Slots < kPbLdsSlots and chunk minima < kPbLdsChunks live in LDS, the rest in a per-wave global area.
 struct PbEntry {
-    float sum;          // reliability sum of the flipped MRB positions (ascending, sequential)
-    unsigned seq;       // insertion number = position in the reference's growing list
-    unsigned pos;       // pos0 | pos1 << 8 | pos2 << 16 | weight << 24  (ascending positions)
+    float sum;          // reliability sum of the flipped MRB positions (ascending, sequential); +inf = removed
+    unsigned pos;       // slots: pos0 | pos1 << 8 | pos2 << 16 | weight << 24;  minima: slot index
 };
-constexpr int kPbLdsEntries = 128;   // typical frontiers stay below this; the rest spills to global memory
+constexpr int kPbLdsSlots = 512, kPbLdsChunks = 64, kPbSuper = 32;   // 32 super-chunks x 4096 slots >= 2 N_max (order 3)
 
 struct __attribute__((aligned(16))) PbLds {
-    double cdfA[65];            // P[Bin(64, p1) <= b]
-    float q[128];               // sigmoid(c4 |y'_p|)
-    PbEntry fr[kPbLdsEntries];  // head of the frontier; the rest spills to global memory
+    double cdfA[65];             // P[Bin(64, p1) <= b]
+    float q[128];                // sigmoid(c4 |y'_p|)
+    PbEntry fr[kPbLdsSlots];     // head of the list
+    PbEntry cmin[kPbLdsChunks];  // chunk minima of the first 4096 slots
+    PbEntry smin[kPbSuper];      // super-chunk minima
 };
 
 struct PbParams {
     int order, nmax;
     float c4;
+    long long cmin_off;          // offset of the spilled chunk minima inside a wave's global area
 };
 
-__device__ __forceinline__ PbEntry fr_get(const PbLds &B, const PbEntry *spill, int i)
+struct PbList {
+    PbLds *B;
+    PbEntry *spill;              // slots >= kPbLdsSlots, then chunk minima >= kPbLdsChunks at cmin_off
+    long long cmin_off;
+    __device__ __forceinline__ PbEntry slot(int i) const { return i < kPbLdsSlots ? B->fr[i] : spill[i - kPbLdsSlots]; }
+    __device__ __forceinline__ void set_slot(int i, PbEntry e) const { if (i < kPbLdsSlots) B->fr[i] = e; else spill[i - kPbLdsSlots] = e; }
+    __device__ __forceinline__ PbEntry cmin(int c) const { return c < kPbLdsChunks ? B->cmin[c] : spill[cmin_off + c - kPbLdsChunks]; }
+    __device__ __forceinline__ void set_cmin(int c, PbEntry e) const { if (c < kPbLdsChunks) B->cmin[c] = e; else spill[cmin_off + c - kPbLdsChunks] = e; }
+};
+
+// wave arg-min on (sum, index): lower index wins ties; result in every lane
+__device__ __forceinline__ void argmin_si(float &s, int &idx, int lane)
 {
-    return i < kPbLdsEntries ? B.fr[i] : spill[i - kPbLdsEntries];
-}
-__device__ __forceinline__ void fr_put(PbLds &B, PbEntry *spill, int i, PbEntry e)
-{
-    if (i < kPbLdsEntries) B.fr[i] = e; else spill[i - kPbLdsEntries] = e;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float os = __shfl(s, lane ^ off, 64);
+        const int oi = __shfl(idx, lane ^ off, 64);
+        if (os < s || (os == s && oi < idx)) { s = os; idx = oi; }
+    }
 }
 
 __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y, const int *__restrict__ index,
@@ -699,6 +720,7 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
                                                      const double *__restrict__ cdf_half /*[65]*/,
                                                      const double *__restrict__ coef /*[64] (64-i)/(i+1)*/,
                                                      PbEntry *__restrict__ spill_all, long long spill_stride,
+                                                     int *__restrict__ queue /* zeroed per launch */,
                                                      u64 *__restrict__ cw_out, float *__restrict__ metric_out,
                                                      int *__restrict__ best_out, int *__restrict__ ntep_out,
                                                      int *__restrict__ aux_out /*[F][4] or null*/)
@@ -713,7 +735,14 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     PbEntry *spill = spill_all + wave * spill_stride;
 
-    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+    // frames are handed out through a device counter: PB-OSD run times differ by orders of magnitude between
+    // frames (a frame on which no rule fires visits all N_max TEPs), a static assignment would wait for the
+    // unluckiest wave
+    for (;;) {
+        int fq = 0;
+        if (lane == 0) fq = atomicAdd(queue, 1);
+        const long long f = __builtin_amdgcn_readfirstlane(fq);
+        if (f >= nframes) break;
         const long long src = index ? index[f] : f;
         const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
         B.q[lane] = 1.0f / (1.0f + det_expf(-(P.c4 * L.w[lane])));
@@ -751,73 +780,93 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
             niu = acc;
         }
         const double p_t_suc = 0.99 * niu, p_t_pro = 0.002 * __builtin_sqrt((1.0 - niu) / (double)P.nmax);
-        if (lane == 0) { PbEntry e0; e0.sum = L.w[63]; e0.seq = 0; e0.pos = 63u | (1u << 24); B.fr[0] = e0; }
+        if (lane == 0) {   // starting point: the single TEP {k-1} (pb_testing.py:109-110)
+            PbEntry e0; e0.sum = L.w[63]; e0.pos = 63u | (1u << 24); B.fr[0] = e0;
+            PbEntry m0; m0.sum = e0.sum; m0.pos = 0; B.cmin[0] = m0; B.smin[0] = m0;
+        }
         wave_fence();
-        int nfr = 1, ntep = P.nmax, bestidx = 0, stop = 0, cmp = 0, suc1 = 0, suc2 = 0;
-        unsigned seq = 1;
+        int nused = 1, nlive = 1, ntep = P.nmax, bestidx = 0, stop = 0, cmp = 0, suc1 = 0, suc2 = 0;
         float best = tep_cost(L, 0.0f, S.d0);
         u64 bestD = S.d0, bestE = 0;
-        for (int j = 0; j < P.nmax - 1 && nfr > 0; ++j) {
-            // first minimum of the frontier in list order
+        const PbList FL{&B, spill, P.cmin_off};
+        for (int j = 0; j < P.nmax - 1 && nlive > 0; ++j) {
+            // first minimum of the list = arg-min on (sum, slot), read off the super-chunk minima
+            const int nsuper = (nused + 4095) >> 12;
             float ms = __builtin_inff();
             int mi = 0x7FFFFFFF;
-            u64 mseq = ~0ull, dummy = 0;
-            for (int t = lane; t < nfr; t += 64) {
-                const PbEntry c = fr_get(B, spill, t);
-                if (c.sum < ms || (c.sum == ms && c.seq < (unsigned)mseq)) { ms = c.sum; mi = t; mseq = c.seq; }
-            }
-            {   // arg-min on (sum, seq); carry the slot index along
-                int key = (int)(unsigned)mseq;
-                u64 slot = (u64)(unsigned)mi;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const float os = __shfl(ms, lane ^ off, 64);
-                    const int ok = __shfl(key, lane ^ off, 64);
-                    const u64 osl = shfl64(slot, lane ^ off);
-                    if (os < ms || (os == ms && (unsigned)ok < (unsigned)key)) { ms = os; key = ok; slot = osl; }
-                }
-                mi = (int)slot;
-                (void)dummy;
-            }
-            cmp += nfr == 1 ? 1 : 2;
-            const PbEntry e = fr_get(B, spill, mi);
+            if (lane < nsuper) { const PbEntry t = B.smin[lane]; ms = t.sum; mi = (int)t.pos; }
+            argmin_si(ms, mi, lane);
+            cmp += nlive == 1 ? 1 : 2;
+            const PbEntry e = FL.slot(mi);
             const int ew = (int)(e.pos >> 24);
             const int p0 = e.pos & 0xFF, pA = (e.pos >> 8) & 0xFF, pB = (e.pos >> 16) & 0xFF;
             const int last = ew == 1 ? p0 : (ew == 2 ? pA : pB);
             const int prev = ew == 2 ? p0 : pA;     // second largest (ew > 1)
+            // children (wave-uniform): extended e U {63}, adjacent = largest index moved down by one
+            PbEntry c1, c2;
+            c1.sum = c2.sum = __builtin_inff(); c1.pos = c2.pos = 0;
+            bool has1 = false, has2 = false;
+            if (last < 63 && ew < P.order) {
+                c1.pos = (e.pos & 0x00FFFFFFu) | (63u << (8 * ew)) | ((unsigned)(ew + 1) << 24);
+                c1.sum = e.sum + L.w[63];
+                has1 = true;
+            }
+            if (ew > 1) {
+                if (last - prev > 1) {
+                    c2.pos = (e.pos & ~(0xFFu << (8 * (ew - 1)))) | ((unsigned)(last - 1) << (8 * (ew - 1)));
+                    const int q0 = c2.pos & 0xFF, q1 = (c2.pos >> 8) & 0xFF, q2 = (c2.pos >> 16) & 0xFF;
+                    float sacc = L.w[q0] + L.w[q1];
+                    if (ew > 2) sacc = sacc + L.w[q2];
+                    c2.sum = sacc;
+                    has2 = true;
+                }
+            } else if (last - 1 > -1) {
+                c2.pos = (unsigned)(last - 1) | (1u << 24);
+                c2.sum = L.w[last - 1];
+                has2 = true;
+            }
+            if (has2 && !has1) { c1 = c2; has1 = true; has2 = false; }      // children in list order: c1 then c2
+            const int s1 = nused, s2 = nused + 1;
             wave_fence();
             if (lane == 0) {
-                --nfr;
-                if (mi != nfr) fr_put(B, spill, mi, fr_get(B, spill, nfr));
-                if (last < 63 && ew < P.order) {            // extended child: e U {63}
-                    PbEntry c = e;
-                    c.pos = (e.pos & 0x00FFFFFFu) | (63u << (8 * ew)) | ((unsigned)(ew + 1) << 24);
-                    c.sum = e.sum + L.w[63];
-                    c.seq = seq++;
-                    fr_put(B, spill, nfr++, c);
-                }
-                if (ew > 1) {                               // adjacent child: largest index moves down by one
-                    if (last - prev > 1) {
-                        PbEntry c = e;
-                        c.pos = (e.pos & ~(0xFFu << (8 * (ew - 1)))) | ((unsigned)(last - 1) << (8 * (ew - 1)));
-                        const int q0 = c.pos & 0xFF, q1 = (c.pos >> 8) & 0xFF, q2 = (c.pos >> 16) & 0xFF;
-                        float sacc = L.w[q0] + L.w[q1];
-                        if (ew > 2) sacc = sacc + L.w[q2];
-                        c.sum = sacc;
-                        c.seq = seq++;
-                        fr_put(B, spill, nfr++, c);
-                    }
-                } else if (last - 1 > -1) {
-                    PbEntry c = e;
-                    c.pos = (unsigned)(last - 1) | (1u << 24);
-                    c.sum = L.w[last - 1];
-                    c.seq = seq++;
-                    fr_put(B, spill, nfr++, c);
-                }
+                PbEntry dead;
+                dead.sum = __builtin_inff(); dead.pos = 0;
+                FL.set_slot(mi, dead);
+                if (has1) FL.set_slot(s1, c1);
+                if (has2) FL.set_slot(s2, c2);
             }
-            nfr = __builtin_amdgcn_readfirstlane(nfr);
-            seq = __builtin_amdgcn_readfirstlane(seq);
+            nused += (has1 ? 1 : 0) + (has2 ? 1 : 0);
+            nlive += (has1 ? 1 : 0) + (has2 ? 1 : 0) - 1;
             __threadfence_block();
+            wave_fence();
+            // refresh the minima: the popped slot's chunk and every chunk that received a child are re-reduced,
+            // then the super-chunks above them (at most two chunks and two super-chunks are touched)
+            const int ck0 = mi >> 6, ck1 = has1 ? (s1 >> 6) : ck0, ck2 = has2 ? (s2 >> 6) : ck0;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int ck = u == 0 ? ck0 : (u == 1 ? ck1 : ck2);
+                if ((u == 1 && ck1 == ck0) || (u == 2 && (ck2 == ck0 || ck2 == ck1))) continue;
+                const int t = ck * 64 + lane;
+                float cs = __builtin_inff();
+                int ci = 0x7FFFFFFF;
+                if (t < nused) { cs = FL.slot(t).sum; ci = t; }
+                argmin_si(cs, ci, lane);
+                if (lane == 0) { PbEntry m; m.sum = cs; m.pos = (unsigned)ci; FL.set_cmin(ck, m); }
+            }
+            __threadfence_block();
+            wave_fence();
+            const int sk0 = ck0 >> 6, sk1 = ck1 >> 6, sk2 = ck2 >> 6;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int sk = u == 0 ? sk0 : (u == 1 ? sk1 : sk2);
+                if ((u == 1 && sk1 == sk0) || (u == 2 && (sk2 == sk0 || sk2 == sk1))) continue;
+                const int c = sk * 64 + lane;
+                float cs = __builtin_inff();
+                int ci = 0x7FFFFFFF;
+                if (c * 64 < nused) { const PbEntry m = FL.cmin(c); cs = m.sum; ci = (int)m.pos; }
+                argmin_si(cs, ci, lane);
+                if (lane == 0) { PbEntry m; m.sum = cs; m.pos = (unsigned)ci; B.smin[sk] = m; }
+            }
             wave_fence();
             // promising-probability rule
             const float rs = e.sum;
@@ -894,6 +943,7 @@ struct OsdState {
     double *d_cdf_half = nullptr;     // PB-OSD: P[Bin(64, 1/2) <= b], b = 0..64
     double *d_coef = nullptr;         // PB-OSD: (64-i)/(i+1)
     void *d_pb_spill = nullptr;       // PB-OSD frontier overflow [waves][stride]
+    int *d_pb_queue = nullptr;        // PB-OSD frame hand-out counter
     int64_t pb_spill_stride = 0;
     int fs_off[4] = {0, 0, 0, 0}, fs_cnt[4] = {0, 0, 0, 0};
     unsigned char *d_perm = nullptr;  // workspace [cap][128]
@@ -967,6 +1017,7 @@ int osd_ctx_init(ldpc_ctx *ctx)
         LDPC_HIP(hipMalloc((void **)&st->d_cdf_half, sizeof(cdf)));
         LDPC_HIP(hipMemcpy(st->d_cdf_half, cdf, sizeof(cdf), hipMemcpyHostToDevice));
         LDPC_HIP(hipMalloc((void **)&st->d_coef, sizeof(coef)));
+        LDPC_HIP(hipMalloc((void **)&st->d_pb_queue, sizeof(int)));
         LDPC_HIP(hipMemcpy(st->d_coef, coef, sizeof(coef), hipMemcpyHostToDevice));
     }
     ctx->osd_ok = true;
@@ -985,6 +1036,7 @@ void osd_ctx_release(ldpc_ctx *ctx)
         (void)hipFree(st->d_cdf_half);
         (void)hipFree(st->d_coef);
         (void)hipFree(st->d_pb_spill);
+        (void)hipFree(st->d_pb_queue);
         delete st;
     }
     ctx->osd_state = nullptr;
@@ -1070,7 +1122,11 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
     if (p->algo == LDPC_OSD_PB) {
         const int64_t nmax = st->ntep[p->order];
         const unsigned blocks = osd_grid(F) < 512 ? osd_grid(F) : 512;       // bounded: each wave owns a spill area
-        const int64_t stride = nmax > kPbLdsEntries ? nmax - kPbLdsEntries + 2 : 2;
+        // the list is append-only: at most 1 + 2 (N_max - 1) slots; spilled slots first, spilled chunk minima after
+        const int64_t slots = 2 * nmax + 2;
+        if (slots > (int64_t)kPbSuper * 4096) return fail(LDPC_E_UNSUPPORTED, "ldpc_osd_decode: PB-OSD list of %lld slots exceeds the kernel's limit", (long long)slots);
+        const int64_t spill_slots = slots > kPbLdsSlots ? slots - kPbLdsSlots : 0;
+        const int64_t stride = spill_slots + (slots / 64 + 2) + 2;
         if (stride > st->pb_spill_stride) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
@@ -1082,11 +1138,12 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
             st->pb_spill_stride = stride;
         }
         PbParams pp;
-        pp.order = p->order; pp.nmax = (int)nmax;
+        pp.order = p->order; pp.nmax = (int)nmax; pp.cmin_off = spill_slots;
         pp.c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)p->snr_db / 10.0)));    // -4 * noise_variance, pb_testing.py:50-52
+        LDPC_HIP(hipMemsetAsync(st->d_pb_queue, 0, sizeof(int), s));
         hipLaunchKernelGGL(osd_pb_kernel, dim3(blocks), dim3(256), 0, s, d_y, d_index, d_count, (long long)F, d_perm,
                            d_parity, pp, st->d_cdf_half, st->d_coef, reinterpret_cast<PbEntry *>(st->d_pb_spill),
-                           (long long)st->pb_spill_stride, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep,
+                           (long long)st->pb_spill_stride, st->d_pb_queue, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep,
                            reinterpret_cast<int *>(p->d_aux));
     } else if (p->algo == LDPC_OSD_FS) {
         FsParams fp;
