@@ -221,27 +221,37 @@ __device__ __forceinline__ void check_row(float (&cv)[32], const float (&tot)[8]
 #define LDPC_VC(t) vc[t] = rot_f<16 - kTerms[BR * 8 + t].s, UP>(tot[kTerms[BR * 8 + t].bc]) - cv[BR * 8 + t];
     LDPC_VC(0) LDPC_VC(1) LDPC_VC(2) LDPC_VC(3) LDPC_VC(4) LDPC_VC(5) LDPC_VC(6) LDPC_VC(7)
 #undef LDPC_VC
-    float m1 = __builtin_fminf(__builtin_fabsf(vc[0]), __builtin_fabsf(vc[1]));
-    float m2 = __builtin_fmaxf(__builtin_fabsf(vc[0]), __builtin_fabsf(vc[1]));
+    // "minimum of the OTHER seven magnitudes" per edge == ((|vc| > m1) ? m1 : m2) of ms_test.py:200-206,
+    // ties included, computed as a shared tree of v_min3: 4 pair minima (the 1e30 clip of :196 rides along as
+    // their third operand -- every output contains at least one clipped node, so the clip reaches all of them),
+    // 2 quad minima, then one v_min3 per edge = 14 min-class instructions per check instead of the 30 of a
+    // running (min1, min2) + compare + select.  min/cmp/cndmask/DPP issue at half the rate of add/mul/xor on
+    // gfx950 (profiles/r01/ubench_valu_issue2.txt), so the per-edge scaling is done with a v_mul instead.
+    float a[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a[t] = __builtin_fabsf(vc[t]);
+    const float p01 = __builtin_fminf(__builtin_fminf(a[0], a[1]), 1e30f), p23 = __builtin_fminf(__builtin_fminf(a[2], a[3]), 1e30f);
+    const float p45 = __builtin_fminf(__builtin_fminf(a[4], a[5]), 1e30f), p67 = __builtin_fminf(__builtin_fminf(a[6], a[7]), 1e30f);
+    const float q03 = __builtin_fminf(p01, p23), q47 = __builtin_fminf(p45, p67);
+    // sign(0) = 0 wipes the whole check row (:187-191): a zero minimum zeroes the scale factor
+    const float aeff = (__builtin_fminf(q03, q47) == 0.0f) ? 0.0f : a_it;
+    float o[8];
+    o[0] = __builtin_fminf(__builtin_fminf(a[1], p23), q47);
+    o[1] = __builtin_fminf(__builtin_fminf(a[0], p23), q47);
+    o[2] = __builtin_fminf(__builtin_fminf(a[3], p01), q47);
+    o[3] = __builtin_fminf(__builtin_fminf(a[2], p01), q47);
+    o[4] = __builtin_fminf(__builtin_fminf(a[5], p67), q03);
+    o[5] = __builtin_fminf(__builtin_fminf(a[4], p67), q03);
+    o[6] = __builtin_fminf(__builtin_fminf(a[7], p45), q03);
+    o[7] = __builtin_fminf(__builtin_fminf(a[6], p45), q03);
     unsigned sx = __float_as_uint(vc[0]) ^ __float_as_uint(vc[1]);
 #pragma unroll
-    for (int t = 2; t < 8; ++t) {
-        const float a = __builtin_fabsf(vc[t]);
-        m2 = __builtin_amdgcn_fmed3f(m1, m2, a);  // second smallest of {m1 <= m2, a}
-        m1 = __builtin_fminf(m1, a);
-        sx ^= __float_as_uint(vc[t]);
-    }
-    const float m1s = a_it * __builtin_fminf(m1, 1e30f);
-    const float m2s = (m1 == 0.0f) ? 0.0f : a_it * __builtin_fminf(m2, 1e30f);
-    // fold the row's sign product into both candidates once; per edge only the edge's own sign bit
-    // is XORed in (v_and + v_xor with VGPR operands run at the fast VALU rate on gfx950, v_bfi and
-    // anything with an SGPR/literal operand at half of it: profiles/r01/ubench_valu_issue2.txt)
-    const unsigned sg = sx & signv;
-    const unsigned m1S = __float_as_uint(m1s) ^ sg, m2S = __float_as_uint(m2s) ^ sg;
+    for (int t = 2; t < 8; ++t) sx ^= __float_as_uint(vc[t]);
+    // cv = (alpha * mag) * S * sign(vc): the product's sign bit is (parity of all signs) ^ (own sign)
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const unsigned sel = (__builtin_fabsf(vc[t]) > m1) ? m1S : m2S;
-        cv[BR * 8 + t] = __uint_as_float(sel ^ (__float_as_uint(vc[t]) & signv));
+        const float mag = aeff * o[t];
+        cv[BR * 8 + t] = __uint_as_float(__float_as_uint(mag) ^ ((sx ^ __float_as_uint(vc[t])) & signv));
     }
 }
 
