@@ -49,6 +49,56 @@ __device__ __forceinline__ u64 shfl64(u64 v, int src)
     return ((u64)hi << 32) | lo;
 }
 
+// ---- wave reductions on DPP (row/bank permutes inside the VALU, ~4 cycles per step) instead of
+// ds_bpermute shuffles (~30 cycles per wave-instruction on gfx950, profiles/r01/ubench_valu_issue.txt).
+// Pattern: xor-1, xor-2 quad permutes, row_half_mirror, row_mirror -> every lane holds its row's result;
+// row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3 -> lane 63 holds the wave's result.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i(int old, int x)
+{
+    return __builtin_amdgcn_update_dpp(old, x, CTRL, ROWMASK, 0xF, false);
+}
+#define LDPC_WAVE_REDUCE(v, OP)                                   \
+    v = OP(v, dpp_i<0xB1, 0xF>(v, v));  /* quad_perm [1,0,3,2] */ \
+    v = OP(v, dpp_i<0x4E, 0xF>(v, v));  /* quad_perm [2,3,0,1] */ \
+    v = OP(v, dpp_i<0x141, 0xF>(v, v)); /* row_half_mirror */     \
+    v = OP(v, dpp_i<0x140, 0xF>(v, v)); /* row_mirror */          \
+    v = OP(v, dpp_i<0x142, 0xA>(ID, v)); /* row_bcast:15 */       \
+    v = OP(v, dpp_i<0x143, 0xC>(ID, v)); /* row_bcast:31 */
+
+__device__ __forceinline__ int op_xor(int a, int b) { return a ^ b; }
+__device__ __forceinline__ int op_min_i(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int op_min_f(int a, int b) { return __float_as_int(__builtin_fminf(__int_as_float(a), __int_as_float(b))); }
+
+// XOR of a 64-bit value over the wave, result in every lane
+__device__ __forceinline__ u64 wave_xor64(u64 x)
+{
+    int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
+    { const int ID = 0; LDPC_WAVE_REDUCE(lo, op_xor) LDPC_WAVE_REDUCE(hi, op_xor) }
+    const unsigned rl = __builtin_amdgcn_readlane(lo, 63), rh = __builtin_amdgcn_readlane(hi, 63);
+    return ((u64)rh << 32) | rl;
+}
+// minimum of non-negative-or-inf floats over the wave, result in every lane
+__device__ __forceinline__ float wave_min_f32(float x)
+{
+    int v = __float_as_int(x);
+    { const int ID = 0x7F800000; LDPC_WAVE_REDUCE(v, op_min_f) }
+    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
+__device__ __forceinline__ int wave_min_i32(int x)
+{
+    int v = x;
+    { const int ID = 0x7FFFFFFF; LDPC_WAVE_REDUCE(v, op_min_i) }
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// lane that holds the smallest (value, index) pair; ties on value go to the lower index
+__device__ __forceinline__ int wave_argmin_lane(float s, int idx)
+{
+    const float m = wave_min_f32(s);
+    const int mi = wave_min_i32(s == m ? idx : 0x7FFFFFFF);
+    return __builtin_ctzll(__ballot(s == m && idx == mi));
+}
+
 // 64x64 bit transpose across the wavefront: in: lane a holds bits b; out: lane b holds bits a
 template <int S>
 __device__ __forceinline__ u64 transpose_stage(u64 x, int lane)
@@ -367,10 +417,7 @@ __device__ __forceinline__ SearchFrame search_prepare_regs(SearchLds &L, const f
         }
     }
     // d0 = (u0 . P') ^ h_parity : XOR-reduce the rows selected by the MRB hard decisions
-    u64 sel = ((S.hm >> lane) & 1) ? Prow : 0ull;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sel ^= shfl64(sel, lane ^ off);
-    S.d0 = sel ^ S.hp;
+    S.d0 = wave_xor64(((S.hm >> lane) & 1) ? Prow : 0ull) ^ S.hp;
     wave_fence();
     return S;
 }
@@ -406,13 +453,11 @@ __device__ __forceinline__ void tep_apply(const SearchLds &L, uchar4 s, u64 d0, 
 // wave arg-min on (cost, index): every lane returns the winner
 __device__ __forceinline__ void wave_argmin(float &best, int &bestt, u64 &bestD, u64 &bestE, int lane)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float oc = __shfl(best, lane ^ off, 64);
-        const int ot = __shfl(bestt, lane ^ off, 64);
-        const u64 oD = shfl64(bestD, lane ^ off), oE = shfl64(bestE, lane ^ off);
-        if (oc < best || (oc == best && ot < bestt)) { best = oc; bestt = ot; bestD = oD; bestE = oE; }
-    }
+    const int w = wave_argmin_lane(best, bestt);
+    best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), w));
+    bestt = __builtin_amdgcn_readlane(bestt, w);
+    bestD = readlane64(bestD, w);
+    bestE = readlane64(bestE, w);
 }
 
 __global__ __launch_bounds__(256) void osd_search_kernel(const float *__restrict__ y, const int *__restrict__ index,
@@ -705,12 +750,9 @@ struct PbList {
 // wave arg-min on (sum, index): lower index wins ties; result in every lane
 __device__ __forceinline__ void argmin_si(float &s, int &idx, int lane)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float os = __shfl(s, lane ^ off, 64);
-        const int oi = __shfl(idx, lane ^ off, 64);
-        if (os < s || (os == s && oi < idx)) { s = os; idx = oi; }
-    }
+    const float m = wave_min_f32(s);
+    idx = wave_min_i32(s == m ? idx : 0x7FFFFFFF);
+    s = m;
 }
 
 __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y, const int *__restrict__ index,
