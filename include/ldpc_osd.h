@@ -208,6 +208,48 @@ int ldpc_osd_counts(ldpc_ctx *ctx, const uint64_t *d_cw, const uint64_t *d_label
                     const int32_t *d_count, const int32_t *d_ntep, int64_t F, int64_t *d_counts, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * H-form OSD primitives for the DL-OSD stage (n = 128, m = k = 64, full-rank H):
+ * DL_OSD_Testing_serial/ordered_statistics_decoding.py.  The trained networks of that stage stay
+ * on the host; these entry points do the per-frame sort / elimination / candidate scan.
+ * ------------------------------------------------------------------------------------- */
+
+/* Host: the TEPs of one order pattern, osd.error_pattern_gen (:81-98): pattern[s] flips inside
+ * segment [bounds[s], bounds[s+1]) of the 64 MRB positions, for s = 0..nseg-1; itertools.product
+ * over the segments (leftmost slowest) of itertools.combinations inside each.
+ * teps: [count][4] u8 {p0, p1, p2, weight} (ascending positions, unused = 0), or NULL to get the
+ * count.  Patterns of total weight > 3 are LDPC_E_UNSUPPORTED.                               */
+int64_t ldpc_hosd_pattern_teps(int32_t nseg, const int32_t *bounds, const int32_t *pattern, uint8_t *teps);
+
+/* check_matrix_reorder + identify_mrb (:25-80, full_gf2elim :222-257) per frame:
+ * positions sorted by ASCENDING |d_order_llr| (ties: lower index first), the columns of H gathered in
+ * that order, Gauss-Jordan with the reference's pivot rule -> [I | M], MRB (last 64) sorted ascending.
+ *   d_lri    [F][128] u8  : lri_p, original bit index at sorted position s                 (:34)
+ *   d_uidx   [F][128] u8  : updated_index_order, sorted position at updated position p       (:67-68)
+ *   d_M      [F][64] u64  : row r of updated_M (bit j = M[r][j], j = updated MRB position)   (:69)
+ *   d_nswaps [F] i32 (nullable): recorded column exchanges, -1 = rank-deficient H (outputs undefined)
+ * The original bit index at updated position p is d_lri[d_uidx[p]]; positions 0..63 are the LRB
+ * (identity part, in the order the elimination left them), 64..127 the MRB.                  */
+int ldpc_hosd_front(ldpc_ctx *ctx, const float *d_order_llr, int64_t F, uint8_t *d_lri, uint8_t *d_uidx,
+                    uint64_t *d_M, int32_t *d_nswaps, void *stream);
+
+/* Block minima of sliding_osd / acquire_min (:153-186): for every frame and every TEP block b
+ * (TEPs d_teps[d_block_off[b] .. d_block_off[b+1]) ), the smallest weighted Hamming distance of
+ *   candidate = [ M . (e xor mrb0), e xor mrb0 ],  mrb0 = hard(d_order_llr) on the MRB     (:154-156,186-187)
+ * to the hard decisions of d_metric_llr, weights |d_metric_llr|                              (:159-160,180-182).
+ * Float order of the metric: positions in updated order, bytes of 8, each byte summed ascending
+ * from 0, the 16 byte sums added ascending (oracle/np_oracle.py hosd_cost).
+ *   d_block_min [F][nblk] f32, d_block_arg [F][nblk] i32 (nullable; index into d_teps of the first minimum)
+ *   d_truth  [F] f32 (nullable, needs d_label_bits [F][2] u64): the metric of the label      (:181-183)
+ *   d_cw     [F][2] u64 (nullable): best candidate over all blocks, ORIGINAL bit order
+ *   d_metric [F] f32, d_best [F] i32 (nullable): its metric and index into d_teps (first minimum)
+ * d_teps: DEVICE [ntep][4] u8 as ldpc_hosd_pattern_teps writes them; d_block_off: DEVICE [nblk+1] i32. */
+int ldpc_hosd_search(ldpc_ctx *ctx, const float *d_order_llr, const float *d_metric_llr, int64_t F,
+                     const uint8_t *d_lri, const uint8_t *d_uidx, const uint64_t *d_M, const uint8_t *d_teps,
+                     const int32_t *d_block_off, int32_t nblk, const uint64_t *d_label_bits, float *d_block_min,
+                     int32_t *d_block_arg, float *d_truth, uint64_t *d_cw, float *d_metric, int32_t *d_best,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * One batch through the whole path with a single host call: the body of the reference drivers'
  * per-batch loops (ldpc_128_testing.py:117-131 then pb_testing.py / fs_testing.py per failed frame):
  *   NMS-T -> error counters -> failed-frame compaction -> OSD (front end + search) on the failures

@@ -11,6 +11,10 @@ records its outputs as small fixtures under tests/golden/:
                         column exchanges                  (Code.gf2elim :7-42, the routine
                         that PB_OSD/pb_testing.py:231-266 ``full_gf2elim`` repeats verbatim)
 
+  gf2elim_ccsds_hform.npz  ascending-|y| column orders of H -> Code.gf2elim output + exchanges (the
+                        same routine as DL_OSD_Testing_serial/ordered_statistics_decoding.py:222-257,
+                        as ``osd.identify_mrb`` :43-80 applies it to the permuted parity-check matrix)
+
 Only DATA is written (inputs and the reference's outputs); no reference source travels.
 The reference tree is imported with bytecode writing disabled so nothing is written there.
 
@@ -84,6 +88,27 @@ def main():
         y=ys, perm=perms.astype(np.int16), reduced=np.packbits(red, axis=2),
         swaps=swaps, nswaps=nswaps)
     print("gf2elim cases", cases, "swaps mean %.2f max %d" % (nswaps.mean(), nswaps.max()))
+
+    # ---- H-form cases: H with columns in ascending-|y| order (DL-OSD stage) ---------------
+    H = code.H
+    m = H.shape[0]
+    hcases = 192
+    hy = np.concatenate([ys[:hcases - 3], ys[-3:]])
+    hperms = np.argsort(np.abs(hy), axis=1, kind="stable")
+    hred = np.empty((hcases, m, n), dtype=np.uint8)
+    hswaps = np.full((hcases, 64, 2), -1, dtype=np.int16)
+    hns = np.zeros(hcases, dtype=np.int16)
+    for i in range(hcases):
+        M, rec = code.gf2elim(np.copy(H[:, hperms[i]]))
+        assert M.shape == (m, n)
+        hred[i] = M
+        hns[i] = len(rec)
+        for t, (a, b) in enumerate(rec):
+            hswaps[i, t] = (a, b)
+    np.savez_compressed(
+        os.path.join(OUT, "gf2elim_ccsds_hform.npz"),
+        y=hy, perm=hperms.astype(np.int16), reduced=np.packbits(hred, axis=2), swaps=hswaps, nswaps=hns)
+    print("H-form gf2elim cases", hcases, "swaps mean %.2f max %d" % (hns.mean(), hns.max()))
 
 
 if __name__ == "__main__":

@@ -572,3 +572,153 @@ def pb_osd_frame(yp, labelp, Gp, order, snr_db):
     fail = None if labelp is None else bool(np.any(best_cw != np.asarray(labelp)))
     return dict(codeword=best_cw, metric=w_dmin, num_teps=num_teps, best_index=best_index,
                 comparisons=comparisons, stop=stop, fail=fail)
+
+
+# --------------------------------------------------------------------------------------
+# DL-OSD stage, H-form primitives:
+#   DL_OSD_Testing_serial/ordered_statistics_decoding.py:25-98,153-257, globalmap.py:57-76,
+#   nn_testing.py:65-82,120-148
+# --------------------------------------------------------------------------------------
+
+
+def segment_boundaries(k, num_seg):
+    """``secure_segment_threshold`` (DL_OSD_Testing_serial/globalmap.py:57-76): a head segment of
+    one position, then num_seg-1 segments growing like 1:2:...; -> (sizes, boundaries)."""
+    alloc = k - 1
+    basic = list(range(1, num_seg))
+    sizes = [int(alloc / sum(basic) * b) for b in basic]
+    sizes[-1] += alloc - sum(sizes)
+    sizes = np.insert(np.array(sizes, dtype=np.int64), 0, 1)
+    return sizes, np.insert(np.cumsum(sizes), 0, 0)
+
+
+def error_pattern_gen(direction, range_list, k):
+    """``osd.error_pattern_gen`` (ordered_statistics_decoding.py:81-98): all error patterns with
+    ``direction[i]`` flips inside segment ``range_list[i]``; itertools.product over the segments
+    of itertools.combinations inside each.  -> int array [N, k]."""
+    per_seg = [list(itertools.combinations(range_list[i], v)) if v else [()] for i, v in enumerate(direction)]
+    joined = list(itertools.product(*per_seg))
+    E = np.zeros((len(joined), k), dtype=np.int64)
+    for r, seq in enumerate(joined):
+        E[r, list(itertools.chain.from_iterable(seq))] = 1
+    return E
+
+
+def convention_path(order_sum):
+    """``query_convention_path`` (nn_testing.py:65-82): 3-segment order patterns with total <= i
+    for i = 0..order_sum, first occurrence kept (UniqueV2 keeps first-seen order)."""
+    path, seen = [], set()
+    for i in range(order_sum + 1):
+        for j1 in range(order_sum + 1):
+            for j2 in range(order_sum + 1):
+                for j3 in range(order_sum + 1):
+                    if j1 + j2 + j3 <= i and (j1, j2, j3) not in seen:
+                        seen.add((j1, j2, j3))
+                        path.append([j1, j2, j3])
+    return path
+
+
+def hosd_reorder(order_llr):
+    """``mag_input_gen`` (:25-28): argsort(|x|) ASCENDING; ties -> lower index first (defined here,
+    tf.argsort leaves it open)."""
+    return np.argsort(np.abs(np.asarray(order_llr, dtype=F32)), kind="stable")
+
+
+def hosd_identify_mrb(H_ordered, k):
+    """``osd.identify_mrb`` (:43-80) for one frame, on H with columns already in ascending
+    reliability order.  -> (updated_index_order[n], updated_M[m,k], swaps).  The LRB part keeps
+    the order the elimination left it in (:69); only the MRB part is sorted (:66-70)."""
+    m, n = H_ordered.shape
+    R, swaps = gf2_eliminate(H_ordered)                        # :55 (same rule as full_gf2elim :222-257)
+    if R.shape[0] != m:
+        raise ValueError("rank-deficient H")
+    idx = np.arange(n)
+    for a, b in swaps:                                         # :58-62
+        idx[a], idx[b] = idx[b], idx[a]
+    mrb = idx[-k:]                                             # :64
+    sw = np.argsort(mrb, kind="stable")                        # :66
+    uidx = np.concatenate([idx[: n - k], mrb[sw]])             # :67-68
+    M = R[:, -k:][:, sw]                                       # :69
+    return uidx, M, swaps
+
+
+def hosd_cost(disc, w):
+    """Canonical float32 order of sum_p disc[p]*w[p] over the 128 updated positions (LRB first):
+    bytes of 8 positions, each summed ascending from 0, then the 16 byte sums added ascending
+    starting from byte 0.  ``disc`` may be [N,128] (vectorised over candidates)."""
+    disc = np.atleast_2d(np.asarray(disc)).astype(F32)
+    w = np.asarray(w, dtype=F32)
+    acc = None
+    for b in range(disc.shape[1] // 8):
+        part = np.zeros(disc.shape[0], dtype=F32)
+        for t in range(8):
+            part = (part + disc[:, 8 * b + t] * w[8 * b + t]).astype(F32)
+        acc = part if acc is None else (acc + part).astype(F32)
+    return acc
+
+
+def hosd_frame(order_llr, metric_llr, label, H, blocks):
+    """One frame of the block evaluation inside ``osd.sliding_osd`` (:164-186) with every block of
+    ``blocks`` (list of [N_b,k] pattern matrices) evaluated by ``acquire_min`` (:153-162).
+
+    order_llr sorts the positions and supplies the starting MRB hard decisions (:174,183-184);
+    metric_llr (trajectory row 0) supplies the hard decisions and weights of the metric
+    (:175,180-182).  -> dict(lri, uidx, perm, M, swaps, block_min, block_arg, truth, best_index,
+    metric, codeword[n] in ORIGINAL bit order)."""
+    order_llr = np.asarray(order_llr, dtype=F32)
+    metric_llr = np.asarray(metric_llr, dtype=F32)
+    m, n = H.shape
+    k = n - m
+    lri = hosd_reorder(order_llr)                              # :34
+    uidx, M, swaps = hosd_identify_mrb(np.asarray(H)[:, lri], k)
+    perm = lri[uidx]
+    o_in, o_orig = order_llr[perm], metric_llr[perm]           # :172-173
+    hard_orig = np.where(o_orig > 0, 0, 1).astype(np.int64)    # :180
+    mag = np.abs(o_orig)                                       # :182
+    initial_mrb = np.where(o_in > 0, 0, 1).astype(np.int64)[-k:]   # :186-187
+    mins, args, off = [], [], 0
+    best = (None, -1, None)
+    for E in blocks:
+        mrb = (np.asarray(E, dtype=np.int64) + initial_mrb[None, :]) % 2      # :154
+        lrb = mrb.dot(M.T) % 2                                                 # :155
+        cand = np.concatenate([lrb, mrb], axis=1)                              # :156
+        cost = hosd_cost((cand + hard_orig[None, :]) % 2, mag)                 # :159-160
+        a = int(np.argmin(cost)) if len(cost) else -1
+        mins.append(cost[a] if a >= 0 else F32(np.inf))
+        args.append(off + a if a >= 0 else -1)
+        if a >= 0 and (best[0] is None or cost[a] < best[0]):
+            best = (cost[a], off + a, cand[a])
+        off += len(cost)
+    truth = None
+    if label is not None:
+        lab = np.asarray(label, dtype=np.int64)[perm]          # :176
+        truth = hosd_cost((lab + hard_orig) % 2, mag)[0]       # :181-183
+    cw = np.zeros(n, dtype=np.int64)
+    if best[2] is not None:
+        cw[perm] = best[2]
+    return dict(lri=lri, uidx=uidx, perm=perm, M=M, swaps=swaps, block_min=np.array(mins, dtype=F32),
+                block_arg=np.array(args, dtype=np.int64), truth=truth, best_index=best[1], metric=best[0],
+                codeword=cw)
+
+
+def sliding_window_decide(block_min, truth, fcn, win, soft_margin, acc_block_size):
+    """The window loop of ``osd.sliding_osd`` (:187-218) replayed on precomputed block minima.
+    ``fcn(x[1, win+1]) -> [p0, p1]``.  -> (success, windows, complexity, global_min)."""
+    window = list(block_min[:win])                             # :188-191
+    global_min = min(window)
+    deep_limit = win
+    for kk in range(len(block_min) - win + 1):                 # :193
+        deep_limit = kk + win
+        if kk != 0:
+            ms = block_min[win + kk - 1]                       # :198-199
+            window.append(ms)
+            window = window[-win:]
+            if ms > global_min:                                # :203-204
+                continue
+        sw = np.sort(np.asarray(window, dtype=F32))            # sliding_window_ops :140-151
+        prob = np.asarray(fcn(np.append(sw, F32(kk)).reshape(1, -1))).reshape(-1)
+        global_min = min(global_min, min(window))
+        if prob[1] > soft_margin:
+            break
+    windows = deep_limit - win + 1                             # :210
+    return bool(global_min == truth), windows, int(acc_block_size[deep_limit]), global_min

@@ -8,6 +8,8 @@ using namespace ldpc;
 namespace ldpc {
 int osd_ctx_init(ldpc_ctx *ctx);      // ldpc_osd.hip
 void osd_ctx_release(ldpc_ctx *ctx);  // ldpc_osd.hip
+int hosd_ctx_init(ldpc_ctx *ctx);     // ldpc_hosd.hip
+void hosd_ctx_release(ldpc_ctx *ctx); // ldpc_hosd.hip
 }  // namespace ldpc
 
 template <typename T>
@@ -48,6 +50,7 @@ int ldpc_ctx_create(const ldpc_code *code, int32_t device, ldpc_ctx **out)
         }
         if ((rc = probe_dpp(&ctx->dpp_ror_up))) break;
         if ((rc = osd_ctx_init(ctx))) break;
+        if ((rc = hosd_ctx_init(ctx))) break;
     } while (0);
     (void)hipSetDevice(prev);
     if (rc) { ldpc_ctx_destroy(ctx); return rc; }
@@ -59,6 +62,7 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx)
 {
     if (!ctx) return;
     osd_ctx_release(ctx);
+    hosd_ctx_release(ctx);
     (void)hipFree(ctx->d_chk_ptr); (void)hipFree(ctx->d_chk_var);
     (void)hipFree(ctx->d_var_ptr); (void)hipFree(ctx->d_var_edge);
     (void)hipFree(ctx->d_blocksum);

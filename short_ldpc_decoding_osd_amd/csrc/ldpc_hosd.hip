@@ -1,0 +1,270 @@
+// H-form ordered-statistics primitives for the DL-OSD stage, (128,64) codes on gfx950 (MI355X).
+//
+// Reference (paths relative to LDPC_128/DL_OSD_Testing_serial/ of the reference):
+//   mag_input_gen / check_matrix_reorder   ordered_statistics_decoding.py:25-41
+//   identify_mrb / full_gf2elim            ordered_statistics_decoding.py:43-80, 222-257
+//   acquire_min / sliding_osd              ordered_statistics_decoding.py:153-186
+//
+// The dual of ldpc_osd.hip: positions are sorted by ASCENDING reliability, the elimination runs
+// on the permuted H (-> [I | M], the identity part on the least reliable independent positions),
+// a candidate is [M . mrb, mrb], and the scan is organised in caller-defined TEP blocks whose
+// minima feed the reference's sliding-window network on the host.  Two separate LLR inputs: one
+// orders the positions and supplies the starting MRB hard decisions (the CNN-refined values in
+// the reference), the other (trajectory row 0) supplies the metric.  One frame per wavefront.
+#include "ldpc_internal.h"
+#include "ldpc_wave.h"
+
+namespace ldpc {
+
+struct __attribute__((aligned(16))) HFrontLds {
+    int abits[128];            // |order_llr| as integer keys
+    u64 colbuf[64];            // M columns in updated MRB order, bit = physical row
+    unsigned mask[4];          // which sorted positions ended up in the MRB
+    unsigned char lri[128];    // sorted position -> original bit
+};
+
+// r += (a > k): ascending ranks
+__device__ __forceinline__ void rank_lt(int &r, int a, int k) { rank_gt(r, k, a); }
+
+__global__ __launch_bounds__(256) void hosd_front_kernel(const float *__restrict__ x, long long F,
+                                                         const u64 *__restrict__ Hcols,
+                                                         unsigned char *__restrict__ lri_out,
+                                                         unsigned char *__restrict__ uidx_out, u64 *__restrict__ M_out,
+                                                         int *__restrict__ nswaps)
+{
+    __shared__ HFrontLds lds[4];
+    const int lane = threadIdx.x & 63;
+    HFrontLds &L = lds[threadIdx.x >> 6];
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+
+    for (long long f = wave; f < F; f += (long long)gridDim.x * 4) {
+        // ---- mag_input_gen (:25-28): rank in ascending |x|, ties -> lower index ------------
+        const int a1 = __float_as_int(x[f * 128 + lane]) & 0x7FFFFFFF;
+        const int a2 = __float_as_int(x[f * 128 + 64 + lane]) & 0x7FFFFFFF;
+        L.abits[lane] = a1;
+        L.abits[lane + 64] = a2;
+        wave_fence();
+        int r1 = 0, r2 = 0;
+#pragma unroll 8
+        for (int u4 = 0; u4 < 32; ++u4) {   // strict compares only; exact ties are repaired below
+            const int4 kq = *reinterpret_cast<const int4 *>(&L.abits[u4 * 4]);
+            rank_lt(r1, a1, kq.x); rank_lt(r2, a2, kq.x);
+            rank_lt(r1, a1, kq.y); rank_lt(r2, a2, kq.y);
+            rank_lt(r1, a1, kq.z); rank_lt(r2, a2, kq.z);
+            rank_lt(r1, a1, kq.w); rank_lt(r2, a2, kq.w);
+        }
+        L.lri[r1] = (unsigned char)lane;
+        L.lri[r2] = (unsigned char)(lane + 64);
+        wave_fence();
+        if (__ballot(L.lri[r1] != lane || L.lri[r2] != lane + 64)) {
+            wave_fence();
+            r1 = 0; r2 = 0;
+            for (int u = 0; u < 128; ++u) {   // "u before v" <=> a_u < a_v or (a_u == a_v and u < v)
+                const int ku = L.abits[u];
+                r1 += (ku < a1) || (ku == a1 && u < lane);
+                r2 += (ku < a2) || (ku == a2 && u < lane + 64);
+            }
+        }
+        wave_fence();
+        L.lri[r1] = (unsigned char)lane;
+        L.lri[r2] = (unsigned char)(lane + 64);
+        if (lane < 4) L.mask[lane] = 0;
+        wave_fence();
+        // ---- H with columns in sorted order (:38-40), column-major, then full_gf2elim (:222-257)
+        const int s1 = L.lri[lane], s2 = L.lri[lane + 64];
+        u64 C1 = Hcols[s1];
+        u64 C2 = Hcols[s2];
+        int rho = lane, idx1 = lane, idx2 = lane + 64;
+        const int ns = ge_columns(C1, C2, rho, idx1, idx2, lane, nullptr);
+        // ---- identify_mrb (:58-69): LRB = index_order[:64] as left by the elimination, MRB sorted
+        atomicOr(&L.mask[idx2 >> 5], 1u << (idx2 & 31));
+        wave_fence();
+        const unsigned m[4] = {L.mask[0], L.mask[1], L.mask[2], L.mask[3]};
+        const int rankM = below_mask(m, idx2);          // updated MRB position of column 64 + lane
+        L.colbuf[rankM] = C2;
+        wave_fence();
+        // rows of updated_M: transpose to (lane = physical row, bit = MRB position), then logical row
+        // r = the row whose pivot sits in column r = physical row rho[r]
+        const u64 R = transpose64(L.colbuf[lane], lane);
+        M_out[f * 64 + lane] = shfl64(R, rho);
+        lri_out[f * 128 + lane] = (unsigned char)s1;
+        lri_out[f * 128 + 64 + lane] = (unsigned char)s2;
+        uidx_out[f * 128 + lane] = (unsigned char)idx1;
+        uidx_out[f * 128 + 64 + rankM] = (unsigned char)idx2;
+        if (nswaps && lane == 0) nswaps[f] = ns;
+        wave_fence();
+    }
+}
+
+struct __attribute__((aligned(16))) HSearchLds {
+    float lut[16][256];   // lut[b][v]: partial metric of discrepancy byte b (updated positions 8b..8b+7)
+    u64 Mcol[64];         // column j of updated_M (bit r = M[r][j])
+    float w[128];         // |metric_llr| in updated order
+    u64 cw[2];
+};
+
+__device__ __forceinline__ float hosd_cost(const HSearchLds &L, u64 DL, u64 DM)
+{
+    float acc = L.lut[0][DL & 0xFF];
+#pragma unroll
+    for (int b = 1; b < 8; ++b) acc = acc + L.lut[b][(DL >> (8 * b)) & 0xFF];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc = acc + L.lut[8 + b][(DM >> (8 * b)) & 0xFF];
+    return acc;
+}
+
+__global__ __launch_bounds__(128) void hosd_search_kernel(const float *__restrict__ xo, const float *__restrict__ xm,
+                                                          long long F, const unsigned char *__restrict__ lri,
+                                                          const unsigned char *__restrict__ uidx,
+                                                          const u64 *__restrict__ Mrows, const uchar4 *__restrict__ teps,
+                                                          const int *__restrict__ block_off, int nblk,
+                                                          const u64 *__restrict__ label, float *__restrict__ block_min,
+                                                          int *__restrict__ block_arg, float *__restrict__ truth,
+                                                          u64 *__restrict__ cw_out, float *__restrict__ metric_out,
+                                                          int *__restrict__ best_out)
+{
+    __shared__ HSearchLds lds[2];
+    const int lane = threadIdx.x & 63;
+    HSearchLds &L = lds[threadIdx.x >> 6];
+    const long long wave = (long long)blockIdx.x * 2 + (threadIdx.x >> 6);
+
+    for (long long f = wave; f < F; f += (long long)gridDim.x * 2) {
+        // original bit index of updated positions lane (LRB) and 64 + lane (MRB)   (:172-176)
+        const int o1 = lri[f * 128 + uidx[f * 128 + lane]];
+        const int o2 = lri[f * 128 + uidx[f * 128 + 64 + lane]];
+        const float m1 = xm[f * 128 + o1], m2 = xm[f * 128 + o2];
+        const float q2 = xo[f * 128 + o2];
+        L.w[lane] = __builtin_fabsf(m1);
+        L.w[64 + lane] = __builtin_fabsf(m2);
+        L.Mcol[lane] = transpose64(Mrows[f * 64 + lane], lane);
+        if (lane < 2) L.cw[lane] = 0;
+        const u64 hgL = __ballot(!(m1 > 0.0f)), hgM = __ballot(!(m2 > 0.0f));   // order_hard_original (:180)
+        const u64 mrb0 = __ballot(!(q2 > 0.0f));                                 // initial_mrb (:186-187)
+        wave_fence();
+        build_byte_luts<16>(L.lut, L.w, lane);
+        // order-0 discrepancies: lrb0 = M . mrb0 (:155), against the metric's hard decisions (:159)
+        const u64 DL0 = wave_xor64(((mrb0 >> lane) & 1) ? L.Mcol[lane] : 0ull) ^ hgL;
+        const u64 DM0 = mrb0 ^ hgM;
+        wave_fence();
+        if (truth) {
+            const u64 l0 = label[f * 2], l1 = label[f * 2 + 1];
+            const u64 labL = __ballot(((o1 < 64 ? l0 : l1) >> (o1 & 63)) & 1);
+            const u64 labM = __ballot(((o2 < 64 ? l0 : l1) >> (o2 & 63)) & 1);
+            const float t = hosd_cost(L, labL ^ hgL, labM ^ hgM);
+            if (lane == 0) truth[f] = t;
+        }
+        float gbest = INFINITY;
+        int gidx = 0x7FFFFFFF;
+        u64 gDL = DL0, gDM = DM0;
+        for (int b = 0; b < nblk; ++b) {
+            const int t0 = block_off[b], t1 = block_off[b + 1];
+            float best = INFINITY;
+            int bestt = 0x7FFFFFFF;
+            u64 bDL = 0, bDM = 0;
+            for (int t = t0 + lane; t < t1; t += 64) {
+                const uchar4 s = teps[t];
+                u64 DL = DL0, DM = DM0;
+                if (s.w > 0) { DL ^= L.Mcol[s.x]; DM ^= 1ull << s.x; }
+                if (s.w > 1) { DL ^= L.Mcol[s.y]; DM ^= 1ull << s.y; }
+                if (s.w > 2) { DL ^= L.Mcol[s.z]; DM ^= 1ull << s.z; }
+                const float c = hosd_cost(L, DL, DM);
+                if (c < best) { best = c; bestt = t; bDL = DL; bDM = DM; }   // ascending t per lane: first minimum
+            }
+            const int wl = wave_argmin_lane(best, bestt);
+            best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), wl));
+            bestt = __builtin_amdgcn_readlane(bestt, wl);
+            bDL = readlane64(bDL, wl);
+            bDM = readlane64(bDM, wl);
+            if (lane == 0) {
+                block_min[f * nblk + b] = best;
+                if (block_arg) block_arg[f * nblk + b] = t1 > t0 ? bestt : -1;
+            }
+            if (best < gbest) { gbest = best; gidx = bestt; gDL = bDL; gDM = bDM; }   // blocks ascend: first minimum
+        }
+        if (lane == 0) {
+            if (metric_out) metric_out[f] = gbest;
+            if (best_out) best_out[f] = gidx == 0x7FFFFFFF ? -1 : gidx;
+        }
+        if (cw_out) {
+            const u64 bitsL = gDL ^ hgL, bitsM = gDM ^ hgM;
+            if ((bitsL >> lane) & 1) atomicOr(&L.cw[o1 >> 6], 1ull << (o1 & 63));
+            if ((bitsM >> lane) & 1) atomicOr(&L.cw[o2 >> 6], 1ull << (o2 & 63));
+            wave_fence();
+            if (lane < 2) cw_out[f * 2 + lane] = L.cw[lane];
+        }
+        wave_fence();
+    }
+}
+
+int hosd_ctx_init(ldpc_ctx *ctx)
+{
+    const ldpc_code &c = ctx->code;
+    ctx->hosd_ok = false;
+    if (c.n != 128 || c.m != 64 || c.k != 64) return LDPC_OK;   // entry points will report UNSUPPORTED
+    std::vector<u64> cols(128, 0);
+    for (int r = 0; r < 64; ++r)
+        for (int v = 0; v < 128; ++v)
+            if (c.H[(size_t)r * 128 + v]) cols[v] |= 1ull << r;
+    LDPC_HIP(hipMalloc((void **)&ctx->d_Hcols, sizeof(u64) * 128));
+    LDPC_HIP(hipMemcpy(ctx->d_Hcols, cols.data(), sizeof(u64) * 128, hipMemcpyHostToDevice));
+    ctx->hosd_ok = true;
+    return LDPC_OK;
+}
+
+void hosd_ctx_release(ldpc_ctx *ctx)
+{
+    (void)hipFree(ctx->d_Hcols);
+    ctx->d_Hcols = nullptr;
+}
+
+static unsigned grid_for(int64_t F, int waves_per_block)
+{
+    const int64_t want = (F + waves_per_block - 1) / waves_per_block;
+    return (unsigned)(want < 1 ? 1 : (want < 8192 ? want : 8192));
+}
+
+}  // namespace ldpc
+
+using namespace ldpc;
+
+extern "C" {
+
+int ldpc_hosd_front(ldpc_ctx *ctx, const float *d_order_llr, int64_t F, uint8_t *d_lri, uint8_t *d_uidx,
+                    uint64_t *d_M, int32_t *d_nswaps, void *stream)
+{
+    if (!ctx || F < 0 || (F > 0 && (!d_order_llr || !d_lri || !d_uidx || !d_M)))
+        return fail(LDPC_E_ARG, "ldpc_hosd_front: bad arguments");
+    if (!ctx->hosd_ok)
+        return fail(LDPC_E_UNSUPPORTED, "H-form OSD kernels need n=128, m=k=64; this code is n=%d m=%d k=%d", ctx->code.n,
+                    ctx->code.m, ctx->code.k);
+    if (F == 0) return LDPC_OK;
+    hipLaunchKernelGGL(hosd_front_kernel, dim3(grid_for(F, 4)), dim3(256), 0, (hipStream_t)stream, d_order_llr, (long long)F,
+                       reinterpret_cast<const u64 *>(ctx->d_Hcols), d_lri, d_uidx, reinterpret_cast<u64 *>(d_M), d_nswaps);
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+int ldpc_hosd_search(ldpc_ctx *ctx, const float *d_order_llr, const float *d_metric_llr, int64_t F,
+                     const uint8_t *d_lri, const uint8_t *d_uidx, const uint64_t *d_M, const uint8_t *d_teps,
+                     const int32_t *d_block_off, int32_t nblk, const uint64_t *d_label_bits, float *d_block_min,
+                     int32_t *d_block_arg, float *d_truth, uint64_t *d_cw, float *d_metric, int32_t *d_best,
+                     void *stream)
+{
+    if (!ctx || F < 0 || nblk < 0 ||
+        (F > 0 && (!d_order_llr || !d_metric_llr || !d_lri || !d_uidx || !d_M || !d_block_off || (nblk > 0 && !d_block_min))))
+        return fail(LDPC_E_ARG, "ldpc_hosd_search: bad arguments");
+    if (d_truth && !d_label_bits) return fail(LDPC_E_ARG, "ldpc_hosd_search: d_truth needs d_label_bits");
+    if (!ctx->hosd_ok)
+        return fail(LDPC_E_UNSUPPORTED, "H-form OSD kernels need n=128, m=k=64; this code is n=%d m=%d k=%d", ctx->code.n,
+                    ctx->code.m, ctx->code.k);
+    if (F == 0) return LDPC_OK;
+    hipLaunchKernelGGL(hosd_search_kernel, dim3(grid_for(F, 2)), dim3(128), 0, (hipStream_t)stream, d_order_llr, d_metric_llr,
+                       (long long)F, d_lri, d_uidx, reinterpret_cast<const u64 *>(d_M),
+                       reinterpret_cast<const uchar4 *>(d_teps), d_block_off, (int)nblk,
+                       reinterpret_cast<const u64 *>(d_label_bits), d_block_min, d_block_arg, d_truth,
+                       reinterpret_cast<u64 *>(d_cw), d_metric, d_best);
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+}  // extern "C"

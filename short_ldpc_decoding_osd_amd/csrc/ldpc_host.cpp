@@ -233,6 +233,48 @@ int64_t tep_table_fs(int k, int w, uint8_t *supports)
     return total;
 }
 
+
+// osd.error_pattern_gen (DL_OSD_Testing_serial/ordered_statistics_decoding.py:81-98): product over
+// the segments (leftmost slowest) of the lexicographic combinations inside each segment
+int64_t hosd_pattern_teps(int nseg, const int32_t *bounds, const int32_t *pattern, uint8_t *teps)
+{
+    if (nseg < 1 || nseg > 64 || !bounds || !pattern) return fail(LDPC_E_ARG, "hosd_pattern_teps: bad arguments");
+    int weight = 0;
+    int64_t total = 1;
+    for (int s = 0; s < nseg; ++s) {
+        const int len = bounds[s + 1] - bounds[s];
+        if (bounds[s] < 0 || bounds[s + 1] > 64 || len < 0 || pattern[s] < 0)
+            return fail(LDPC_E_ARG, "hosd_pattern_teps: segment %d = [%d, %d), %d flips", s, bounds[s], bounds[s + 1], pattern[s]);
+        weight += pattern[s];
+        total *= pattern[s] > len ? 0 : binom(len, pattern[s]);   // combinations() of too many items is empty
+    }
+    if (weight > 3) return fail(LDPC_E_UNSUPPORTED, "hosd_pattern_teps: pattern weight %d > 3", weight);
+    if (!teps || total == 0) return total;
+    // odometer over the flipped positions: slot q belongs to segment seg[q], slots of one segment ascend
+    int seg[3], pos[3];
+    int w = 0;
+    for (int s = 0; s < nseg; ++s)
+        for (int q = 0; q < pattern[s]; ++q) { seg[w] = s; pos[w] = bounds[s] + q; ++w; }
+    for (int64_t t = 0; t < total; ++t) {
+        uint8_t *dst = teps + 4 * t;
+        dst[0] = dst[1] = dst[2] = 0;
+        for (int q = 0; q < w; ++q) dst[q] = (uint8_t)pos[q];
+        dst[3] = (uint8_t)w;
+        // advance: rightmost slot that can still move inside its segment
+        int q = w - 1;
+        while (q >= 0) {
+            int after = 0;   // slots of the same segment to the right of q
+            for (int z = q + 1; z < w && seg[z] == seg[q]; ++z) ++after;
+            if (pos[q] < bounds[seg[q] + 1] - 1 - after) break;
+            --q;
+        }
+        if (q < 0) break;
+        ++pos[q];
+        for (int z = q + 1; z < w; ++z) pos[z] = seg[z] == seg[z - 1] ? pos[z - 1] + 1 : bounds[seg[z]];
+    }
+    return total;
+}
+
 }  // namespace ldpc
 
 using namespace ldpc;
@@ -351,5 +393,10 @@ uint32_t ldpc_crc32c(const void *data, uint64_t len)
 }
 
 int64_t ldpc_tep_table_fs(int32_t k, int32_t weight, uint8_t *supports) { return tep_table_fs(k, weight, supports); }
+
+int64_t ldpc_hosd_pattern_teps(int32_t nseg, const int32_t *bounds, const int32_t *pattern, uint8_t *teps)
+{
+    return hosd_pattern_teps(nseg, bounds, pattern, teps);
+}
 
 }  // extern "C"

@@ -54,10 +54,12 @@ struct ldpc_ctx {
     // OSD constants (n = 128, k = 64 only)
     uint64_t *d_Gcols = nullptr;   // [128] column v of G as a 64-bit word (bit r = G[r][v])
     uint8_t *d_tep = nullptr;      // TEP supports, order <= 3: [43745][4] (i, j, l, weight)
+    uint64_t *d_Hcols = nullptr;   // [128] column v of H as a 64-bit word (bit r = H[r][v]); n = 128, m = 64 only
     int32_t *d_blocksum = nullptr; // compaction scratch
     int64_t blocksum_cap = 0;
     bool dpp_ror_up = true;        // probed: row_ror:n moves data towards higher lanes
     bool osd_ok = false;
+    bool hosd_ok = false;
     void *osd_state = nullptr;     // ldpc::OsdState (TEP table sizes, front-end workspace)
     hipEvent_t *timing = nullptr;  // [LDPC_TIMING_SLOTS][6] events of ldpc_pipeline_run, created on first use
 };
@@ -69,6 +71,7 @@ int gf2elim(int32_t *M, int m, int n, std::vector<int32_t> *swaps);  // returns 
 int build_code(ldpc_code &c);  // fills G, graph tables, qc flag from c.H/m/n
 int64_t tep_table(int k, int order, uint8_t *supports, int64_t *boundaries);
 int64_t tep_table_fs(int k, int w, uint8_t *supports);
+int64_t hosd_pattern_teps(int nseg, const int32_t *bounds, const int32_t *pattern, uint8_t *teps);
 
 // launchers (one per .hip file)
 int launch_nms(ldpc_ctx *ctx, const float *d_llr, int64_t B, int T, const float *alpha, float w_in, float w_out,

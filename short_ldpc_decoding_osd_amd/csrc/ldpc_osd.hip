@@ -25,179 +25,10 @@
 #include <stdlib.h>
 
 #include "ldpc_internal.h"
+#include "ldpc_wave.h"
 
 namespace ldpc {
 
-typedef unsigned long long u64;
-
-constexpr int kOsdN = 128, kOsdK = 64;
-
-// ---------------------------------------------------------------------------------------
-// wave-level helpers
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 readlane64(u64 v, int lane)
-{
-    unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, lane);
-    unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
-    return ((u64)hi << 32) | lo;
-}
-
-__device__ __forceinline__ u64 shfl64(u64 v, int src)
-{
-    unsigned lo = __shfl((int)(unsigned)v, src, 64);
-    unsigned hi = __shfl((int)(unsigned)(v >> 32), src, 64);
-    return ((u64)hi << 32) | lo;
-}
-
-// ---- wave reductions on DPP (row/bank permutes inside the VALU, ~4 cycles per step) instead of
-// ds_bpermute shuffles (~30 cycles per wave-instruction on gfx950, profiles/r01/ubench_valu_issue.txt).
-// Pattern: xor-1, xor-2 quad permutes, row_half_mirror, row_mirror -> every lane holds its row's result;
-// row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3 -> lane 63 holds the wave's result.
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ int dpp_i(int old, int x)
-{
-    return __builtin_amdgcn_update_dpp(old, x, CTRL, ROWMASK, 0xF, false);
-}
-#define LDPC_WAVE_REDUCE(v, OP)                                   \
-    v = OP(v, dpp_i<0xB1, 0xF>(v, v));  /* quad_perm [1,0,3,2] */ \
-    v = OP(v, dpp_i<0x4E, 0xF>(v, v));  /* quad_perm [2,3,0,1] */ \
-    v = OP(v, dpp_i<0x141, 0xF>(v, v)); /* row_half_mirror */     \
-    v = OP(v, dpp_i<0x140, 0xF>(v, v)); /* row_mirror */          \
-    v = OP(v, dpp_i<0x142, 0xA>(ID, v)); /* row_bcast:15 */       \
-    v = OP(v, dpp_i<0x143, 0xC>(ID, v)); /* row_bcast:31 */
-
-__device__ __forceinline__ int op_xor(int a, int b) { return a ^ b; }
-__device__ __forceinline__ int op_min_i(int a, int b) { return a < b ? a : b; }
-__device__ __forceinline__ int op_min_f(int a, int b) { return __float_as_int(__builtin_fminf(__int_as_float(a), __int_as_float(b))); }
-
-// XOR of a 64-bit value over the wave, result in every lane
-__device__ __forceinline__ u64 wave_xor64(u64 x)
-{
-    int lo = (int)(unsigned)x, hi = (int)(unsigned)(x >> 32);
-    { const int ID = 0; LDPC_WAVE_REDUCE(lo, op_xor) LDPC_WAVE_REDUCE(hi, op_xor) }
-    const unsigned rl = __builtin_amdgcn_readlane(lo, 63), rh = __builtin_amdgcn_readlane(hi, 63);
-    return ((u64)rh << 32) | rl;
-}
-// minimum of non-negative-or-inf floats over the wave, result in every lane
-__device__ __forceinline__ float wave_min_f32(float x)
-{
-    int v = __float_as_int(x);
-    { const int ID = 0x7F800000; LDPC_WAVE_REDUCE(v, op_min_f) }
-    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
-}
-__device__ __forceinline__ int wave_min_i32(int x)
-{
-    int v = x;
-    { const int ID = 0x7FFFFFFF; LDPC_WAVE_REDUCE(v, op_min_i) }
-    return __builtin_amdgcn_readlane(v, 63);
-}
-// lane that holds the smallest (value, index) pair; ties on value go to the lower index
-__device__ __forceinline__ int wave_argmin_lane(float s, int idx)
-{
-    const float m = wave_min_f32(s);
-    const int mi = wave_min_i32(s == m ? idx : 0x7FFFFFFF);
-    return __builtin_ctzll(__ballot(s == m && idx == mi));
-}
-
-// 64x64 bit transpose across the wavefront: in: lane a holds bits b; out: lane b holds bits a
-template <int S>
-__device__ __forceinline__ u64 transpose_stage(u64 x, int lane)
-{
-    constexpr u64 m = S == 32 ? 0x00000000FFFFFFFFull : S == 16 ? 0x0000FFFF0000FFFFull : S == 8 ? 0x00FF00FF00FF00FFull
-                    : S == 4 ? 0x0F0F0F0F0F0F0F0Full : S == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
-    const u64 p = shfl64(x, lane ^ S);
-    return (lane & S) ? (((p >> S) & m) | (x & ~m)) : ((x & m) | ((p & m) << S));
-}
-
-__device__ __forceinline__ u64 transpose64(u64 x, int lane)
-{
-    x = transpose_stage<32>(x, lane);
-    x = transpose_stage<16>(x, lane);
-    x = transpose_stage<8>(x, lane);
-    x = transpose_stage<4>(x, lane);
-    x = transpose_stage<2>(x, lane);
-    x = transpose_stage<1>(x, lane);
-    return x;
-}
-
-__device__ __forceinline__ void wave_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// ---------------------------------------------------------------------------------------
-// Gauss-Jordan over GF(2), column-major in registers (full_gf2elim, pb_testing.py:231-266).
-//   C1/C2 : columns lane / lane+64, bit = PHYSICAL row
-//   rho   : lane l = logical row l -> physical row (row exchanges only permute this map)
-//   idx1/2: the reference's index_order entry travelling with each column (:276-281)
-// For i = j = 0..63:  first logical row >= i with a 1 in column i becomes the pivot (:238-245);
-// if there is none, column i is exchanged with the first column >= i in which logical row i has
-// a 1 and the pair is recorded (:251-256); then column i is cleared in every other row (:258-262).
-// Returns the number of column exchanges, or -1 for a rank-deficient matrix.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1, int &idx2, int lane,
-                                          unsigned char *swaps /* LDS or global [64][2], may be null */)
-{
-    int nsw = 0;
-    u64 ge_i = ~0ull;   // lanes (logical rows) >= i
-    for (unsigned i = 0; i < (unsigned)kOsdK; ++i, ge_i <<= 1) {
-        u64 cj = readlane64(C1, i);
-        const u64 bal = __ballot((cj >> rho) & 1) & ge_i;
-        unsigned r;
-        if (bal == 0) {
-            const int pri = __builtin_amdgcn_readlane(rho, i);
-            const u64 b1 = __ballot((C1 >> pri) & 1) & ge_i;
-            unsigned col;
-            if (b1) col = __builtin_ctzll(b1);
-            else {
-                const u64 b2 = __ballot((C2 >> pri) & 1);
-                if (b2 == 0) return -1;
-                col = 64 + __builtin_ctzll(b2);
-            }
-            // (select form on purpose: branching on col < 64 makes the compiler spill C1/C2 to scratch)
-            const unsigned cl = col & 63;
-            const bool lo = col < 64;
-            const u64 cc1 = readlane64(C1, cl), cc2 = readlane64(C2, cl);
-            const int ic1 = __builtin_amdgcn_readlane(idx1, cl), ic2 = __builtin_amdgcn_readlane(idx2, cl);
-            const u64 cc = lo ? cc1 : cc2;
-            const int ic = lo ? ic1 : ic2;
-            const int ii = __builtin_amdgcn_readlane(idx1, i);
-            const bool hit = (unsigned)lane == cl;
-            C1 = (hit && lo) ? cj : C1;
-            idx1 = (hit && lo) ? ii : idx1;
-            C2 = (hit && !lo) ? cj : C2;
-            idx2 = (hit && !lo) ? ii : idx2;
-            C1 = ((unsigned)lane == i) ? cc : C1;
-            idx1 = ((unsigned)lane == i) ? ic : idx1;
-            if (swaps && lane == 0) { swaps[2 * nsw] = (unsigned char)i; swaps[2 * nsw + 1] = (unsigned char)col; }
-            ++nsw;
-            cj = readlane64(C1, i);   // re-read instead of carrying `cc`: keeps the pivot column in SGPRs on both paths
-            r = i;
-        } else {
-            r = __builtin_ctzll(bal);
-        }
-        const int pr = __builtin_amdgcn_readlane(rho, r);
-        if (r != i) {   // exchange logical rows i and r: two lanes of the row map, no data moves
-            const int pi = __builtin_amdgcn_readlane(rho, i);
-            // (lane select through M0: a VALU instruction may read only one SGPR on gfx9)
-            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(rho) : "s"(pr), "s"(i) : "m0");
-            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(rho) : "s"(pi), "s"(r) : "m0");
-        }
-        const u64 e = cj & ~(1ull << pr);
-        if (e != 0) {   // nothing to clear when the pivot column is already a unit vector (common: G = [P | I])
-            const unsigned bit = 1u << (pr & 31);
-            if (pr < 32) {   // wave-uniform: test the half that holds physical row pr without a 64-bit shift
-                if ((unsigned)C1 & bit) C1 ^= e;
-                if ((unsigned)C2 & bit) C2 ^= e;
-            } else {
-                if ((unsigned)(C1 >> 32) & bit) C1 ^= e;
-                if ((unsigned)(C2 >> 32) & bit) C2 ^= e;
-            }
-        }
-    }
-    return nsw;
-}
 
 // ---------------------------------------------------------------------------------------
 // ldpc_osd_ge: elimination of caller-supplied matrices (row-major in, row-major out)
@@ -240,24 +71,6 @@ struct FrontResult {
     int ns;       // recorded column exchanges (-1: rank-deficient)
 };
 
-// r += (k > a) as v_cmp_gt_i32 + v_addc through VCC (both 4-byte encodings)
-__device__ __forceinline__ void rank_gt(int &r, int a, int k)
-{
-    asm("v_cmp_gt_i32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(r) : "v"(a), "v"(k) : "vcc");
-}
-
-__device__ __forceinline__ int below_mask(const unsigned (&m)[4], int x)
-{
-    // number of set bits of the 128-bit mask strictly below position x
-    int c = 0;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const int t = x - 32 * d;
-        const unsigned bm = t <= 0 ? 0u : (t >= 32 ? 0xFFFFFFFFu : ((1u << t) - 1u));
-        c += __popc(m[d] & bm);
-    }
-    return c;
-}
 
 // sort + column gather + elimination + bookkeeping of one frame (one wavefront); results in registers
 __device__ __forceinline__ FrontResult front_device(FrontLds &L, const float *__restrict__ y, long long src,
@@ -391,31 +204,7 @@ __device__ __forceinline__ SearchFrame search_prepare_regs(SearchLds &L, const f
     S.hm = __ballot(!(y1 > 0.0f));
     S.hp = __ballot(!(y2 > 0.0f));
     wave_fence();
-    // byte LUTs, lut[b][v] = sum over the set bits t of v (ascending t) of |y'[64 + 8 b + t]|.
-    // Lane l owns the entries whose low five index bits equal l & 31 and whose top index bit equals
-    // l >> 5 (4 x 8 = 32 entries): within each 32-lane LDS group the stores of one instruction then
-    // hit 32 distinct banks.  (Letting a lane fill 32 CONSECUTIVE entries puts all 64 lanes on one
-    // bank per store: 32-way conflicts, which cost as much LDS time as all the lookups of the scan.)
-    {
-        const int lo5 = lane & 31, top = lane >> 5;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const float4 wa = *reinterpret_cast<const float4 *>(&L.w[64 + 8 * b]);       // broadcast reads
-            const float4 wb = *reinterpret_cast<const float4 *>(&L.w[64 + 8 * b + 4]);
-            float base = 0.0f;
-            base = base + ((lo5 & 1) ? wa.x : 0.0f);
-            base = base + ((lo5 & 2) ? wa.y : 0.0f);
-            base = base + ((lo5 & 4) ? wa.z : 0.0f);
-            base = base + ((lo5 & 8) ? wa.w : 0.0f);
-            base = base + ((lo5 & 16) ? wb.x : 0.0f);
-            const float h7 = top ? wb.w : 0.0f;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {   // index bits 5, 6 = h, bit 7 = top
-                const float v5 = (h & 1) ? wb.y : 0.0f, v6 = (h & 2) ? wb.z : 0.0f;
-                L.lut[b][(top * 4 + h) * 32 + lo5] = ((base + v5) + v6) + h7;
-            }
-        }
-    }
+    build_byte_luts<8>(L.lut, &L.w[64], lane);
     // d0 = (u0 . P') ^ h_parity : XOR-reduce the rows selected by the MRB hard decisions
     S.d0 = wave_xor64(((S.hm >> lane) & 1) ? Prow : 0ull) ^ S.hp;
     wave_fence();

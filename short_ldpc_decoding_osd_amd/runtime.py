@@ -204,6 +204,45 @@ class Decoder:
                                           _ptr(out["ntep"]), self._stream()), "ldpc_osd_search")
         return out
 
+    # ------------------------------------------------------------------ H-form OSD (DL-OSD stage)
+    def hosd_front(self, order_llr):
+        """check_matrix_reorder + identify_mrb on [F,128] ordering values.  Returns (lri[F,128] u8,
+        uidx[F,128] u8, M[F,64] int64 rows of updated_M, nswaps[F] int32)."""
+        self._chk(order_llr, torch.float32, (self.n,), "order_llr")
+        F = order_llr.shape[0]
+        lri = self.empty((F, 128), torch.uint8)
+        uidx = self.empty((F, 128), torch.uint8)
+        M = self.empty((F, 64), torch.int64)
+        ns = self.empty((F,), torch.int32)
+        _lib.check(self.L.ldpc_hosd_front(self._ctx, _ptr(order_llr), F, _ptr(lri), _ptr(uidx), _ptr(M), _ptr(ns),
+                                          self._stream()), "ldpc_hosd_front")
+        return lri, uidx, M, ns
+
+    def hosd_search(self, order_llr, metric_llr, front, teps, block_off, label_bits=None, want_arg=True, want_best=True):
+        """Block minima over the TEP blocks ``teps[block_off[b]:block_off[b+1]]`` (device tensors: [Nt,4] u8,
+        [nblk+1] int32).  Returns dict(block_min[F,nblk], block_arg, truth, cw, metric, best)."""
+        self._chk(order_llr, torch.float32, (self.n,), "order_llr")
+        self._chk(metric_llr, torch.float32, (self.n,), "metric_llr")
+        lri, uidx, M = front[:3]
+        F = order_llr.shape[0]
+        if metric_llr.shape[0] != F or lri.shape[0] != F:
+            raise ValueError("order_llr, metric_llr and the front-end results must hold the same frames")
+        self._chk(teps, torch.uint8, (4,), "teps")
+        if block_off.dtype != torch.int32 or block_off.device != self.device or block_off.dim() != 1 or block_off.numel() < 1:
+            raise ValueError("block_off: expected a 1-D int32 tensor [nblk+1] on the device")
+        nblk = block_off.numel() - 1
+        out = dict(block_min=self.empty((F, nblk), torch.float32),
+                   block_arg=self.empty((F, nblk), torch.int32) if want_arg else None,
+                   truth=self.empty((F,), torch.float32) if label_bits is not None else None,
+                   cw=self.empty((F, 2), torch.int64) if want_best else None,
+                   metric=self.empty((F,), torch.float32) if want_best else None,
+                   best=self.empty((F,), torch.int32) if want_best else None)
+        _lib.check(self.L.ldpc_hosd_search(self._ctx, _ptr(order_llr), _ptr(metric_llr), F, _ptr(lri), _ptr(uidx), _ptr(M),
+                                           _ptr(teps), _ptr(block_off), nblk, _ptr(label_bits), _ptr(out["block_min"]),
+                                           _ptr(out["block_arg"]), _ptr(out["truth"]), _ptr(out["cw"]), _ptr(out["metric"]),
+                                           _ptr(out["best"]), self._stream()), "ldpc_hosd_search")
+        return out
+
     def osd_counts(self, cw, label_bits, index=None, count=None, ntep=None, counts=None, F=None):
         """counts[3] += {frames, frames_wrong, teps_total}; labels are looked up through index."""
         F = cw.shape[0] if F is None else F
