@@ -96,11 +96,17 @@ __global__ __launch_bounds__(256) void hosd_front_kernel(const float *__restrict
     }
 }
 
+constexpr int kHosdMaxBlocks = 1024;   // keys kept in LDS (8 KiB); the reference's paths have 30 blocks
+constexpr int kHosdChunk = 256;        // TEPs per work item (a block larger than this is split)
+
 struct __attribute__((aligned(16))) HSearchLds {
     float lut[16][256];   // lut[b][v]: partial metric of discrepancy byte b (updated positions 8b..8b+7)
     u64 Mcol[64];         // column j of updated_M (bit r = M[r][j])
     float w[128];         // |metric_llr| in updated order
-    u64 cw[2];
+    u64 keys[kHosdMaxBlocks];   // per block: (metric bits << 32) | TEP index, minimum = first minimum
+    u64 hgL, hgM, mrb0, DL0, best, cw[2];
+    int ticket;
+    unsigned char o[128]; // original bit index of updated position p
 };
 
 __device__ __forceinline__ float hosd_cost(const HSearchLds &L, u64 DL, u64 DM)
@@ -113,7 +119,18 @@ __device__ __forceinline__ float hosd_cost(const HSearchLds &L, u64 DL, u64 DM)
     return acc;
 }
 
-__global__ __launch_bounds__(128) void hosd_search_kernel(const float *__restrict__ xo, const float *__restrict__ xm,
+__device__ __forceinline__ void hosd_apply(const HSearchLds &L, uchar4 s, u64 &DL, u64 &DM)
+{
+    if (s.w > 0) { DL ^= L.Mcol[s.x]; DM ^= 1ull << s.x; }
+    if (s.w > 1) { DL ^= L.Mcol[s.y]; DM ^= 1ull << s.y; }
+    if (s.w > 2) { DL ^= L.Mcol[s.z]; DM ^= 1ull << s.z; }
+}
+
+// One frame per 256-thread workgroup: the four wavefronts share the frame's LUTs and pull work items
+// (a TEP block, or a 256-TEP slice of a large one) from an LDS ticket counter; per-block minima are
+// combined with 64-bit LDS atomics on (metric bits, TEP index) keys -- metrics are sums of magnitudes,
+// so their bit patterns order like the floats and the smallest key is the FIRST minimum.
+__global__ __launch_bounds__(256) void hosd_search_kernel(const float *__restrict__ xo, const float *__restrict__ xm,
                                                           long long F, const unsigned char *__restrict__ lri,
                                                           const unsigned char *__restrict__ uidx,
                                                           const u64 *__restrict__ Mrows, const uchar4 *__restrict__ teps,
@@ -123,76 +140,105 @@ __global__ __launch_bounds__(128) void hosd_search_kernel(const float *__restric
                                                           u64 *__restrict__ cw_out, float *__restrict__ metric_out,
                                                           int *__restrict__ best_out)
 {
-    __shared__ HSearchLds lds[2];
-    const int lane = threadIdx.x & 63;
-    HSearchLds &L = lds[threadIdx.x >> 6];
-    const long long wave = (long long)blockIdx.x * 2 + (threadIdx.x >> 6);
+    __shared__ HSearchLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (long long f = wave; f < F; f += (long long)gridDim.x * 2) {
-        // original bit index of updated positions lane (LRB) and 64 + lane (MRB)   (:172-176)
-        const int o1 = lri[f * 128 + uidx[f * 128 + lane]];
-        const int o2 = lri[f * 128 + uidx[f * 128 + 64 + lane]];
-        const float m1 = xm[f * 128 + o1], m2 = xm[f * 128 + o2];
-        const float q2 = xo[f * 128 + o2];
-        L.w[lane] = __builtin_fabsf(m1);
-        L.w[64 + lane] = __builtin_fabsf(m2);
-        L.Mcol[lane] = transpose64(Mrows[f * 64 + lane], lane);
-        if (lane < 2) L.cw[lane] = 0;
-        const u64 hgL = __ballot(!(m1 > 0.0f)), hgM = __ballot(!(m2 > 0.0f));   // order_hard_original (:180)
-        const u64 mrb0 = __ballot(!(q2 > 0.0f));                                 // initial_mrb (:186-187)
-        wave_fence();
-        build_byte_luts<16>(L.lut, L.w, lane);
-        // order-0 discrepancies: lrb0 = M . mrb0 (:155), against the metric's hard decisions (:159)
-        const u64 DL0 = wave_xor64(((mrb0 >> lane) & 1) ? L.Mcol[lane] : 0ull) ^ hgL;
-        const u64 DM0 = mrb0 ^ hgM;
-        wave_fence();
-        if (truth) {
+    for (long long f = blockIdx.x; f < F; f += gridDim.x) {
+        // ---- phase 0: values in updated order (:172-176), hard decisions, M columns, key reset --------
+        if (tid < 128) {
+            const int o = lri[f * 128 + uidx[f * 128 + tid]];
+            const float m = xm[f * 128 + o];
+            L.o[tid] = (unsigned char)o;
+            L.w[tid] = __builtin_fabsf(m);
+            const u64 hg = __ballot(!(m > 0.0f));                       // order_hard_original (:180)
+            if (wave == 0) { if (lane == 0) L.hgL = hg; }
+            else {
+                const u64 h0 = __ballot(!(xo[f * 128 + o] > 0.0f));      // initial_mrb (:186-187)
+                if (lane == 0) { L.hgM = hg; L.mrb0 = h0; }
+            }
+        } else if (wave == 2) {
+            L.Mcol[lane] = transpose64(Mrows[f * 64 + lane], lane);
+        } else {
+            if (lane == 0) { L.ticket = 0; L.best = ~0ull; L.cw[0] = 0; L.cw[1] = 0; }
+        }
+        for (int b = tid; b < nblk; b += 256) L.keys[b] = ~0ull;
+        __syncthreads();
+        // ---- phase 1: byte LUTs (four per wavefront), order-0 discrepancy of the LRB part (:155,:159) --
+        build_byte_luts<4>(&L.lut[4 * wave], &L.w[32 * wave], lane);
+        if (wave == 0) {
+            const u64 d = wave_xor64(((L.mrb0 >> lane) & 1) ? L.Mcol[lane] : 0ull) ^ L.hgL;
+            if (lane == 0) L.DL0 = d;
+        }
+        __syncthreads();
+        const u64 DL0 = L.DL0, DM0 = L.mrb0 ^ L.hgM;
+        if (truth && wave == 1) {
             const u64 l0 = label[f * 2], l1 = label[f * 2 + 1];
+            const int o1 = L.o[lane], o2 = L.o[64 + lane];
             const u64 labL = __ballot(((o1 < 64 ? l0 : l1) >> (o1 & 63)) & 1);
             const u64 labM = __ballot(((o2 < 64 ? l0 : l1) >> (o2 & 63)) & 1);
-            const float t = hosd_cost(L, labL ^ hgL, labM ^ hgM);
+            const float t = hosd_cost(L, labL ^ L.hgL, labM ^ L.hgM);     // (:181-183)
             if (lane == 0) truth[f] = t;
         }
-        float gbest = INFINITY;
-        int gidx = 0x7FFFFFFF;
-        u64 gDL = DL0, gDM = DM0;
-        for (int b = 0; b < nblk; ++b) {
-            const int t0 = block_off[b], t1 = block_off[b + 1];
-            float best = INFINITY;
-            int bestt = 0x7FFFFFFF;
-            u64 bDL = 0, bDM = 0;
-            for (int t = t0 + lane; t < t1; t += 64) {
-                const uchar4 s = teps[t];
-                u64 DL = DL0, DM = DM0;
-                if (s.w > 0) { DL ^= L.Mcol[s.x]; DM ^= 1ull << s.x; }
-                if (s.w > 1) { DL ^= L.Mcol[s.y]; DM ^= 1ull << s.y; }
-                if (s.w > 2) { DL ^= L.Mcol[s.z]; DM ^= 1ull << s.z; }
-                const float c = hosd_cost(L, DL, DM);
-                if (c < best) { best = c; bestt = t; bDL = DL; bDM = DM; }   // ascending t per lane: first minimum
+        // ---- phase 2: the scan; items are numbered block by block, slice by slice -----------------------
+        {
+            int item = 0, b = 0, s = nblk > 0 ? block_off[0] : 0, t1 = nblk > 0 ? block_off[1] : 0;
+            for (;;) {
+                int want = 0;
+                if (lane == 0) want = atomicAdd(&L.ticket, 1);
+                want = __builtin_amdgcn_readfirstlane(want);
+                // advance (b, s) to item `want`; empty blocks own no item
+                while (b < nblk) {
+                    if (s >= t1) { ++b; if (b < nblk) { s = block_off[b]; t1 = block_off[b + 1]; } continue; }
+                    if (item == want) break;
+                    ++item; s += kHosdChunk;
+                }
+                if (b >= nblk) break;
+                const int e = s + kHosdChunk < t1 ? s + kHosdChunk : t1;
+                float best = INFINITY;
+                int bestt = 0x7FFFFFFF;
+                for (int t = s + lane; t < e; t += 64) {
+                    u64 DL = DL0, DM = DM0;
+                    hosd_apply(L, teps[t], DL, DM);
+                    const float c = hosd_cost(L, DL, DM);
+                    if (c < best) { best = c; bestt = t; }                 // ascending t per lane: first minimum
+                }
+                const int wl = wave_argmin_lane(best, bestt);
+                if (lane == wl)
+                    atomicMin(&L.keys[b], ((u64)(unsigned)__float_as_int(best) << 32) | (unsigned)bestt);
+                ++item; s += kHosdChunk;
             }
-            const int wl = wave_argmin_lane(best, bestt);
-            best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), wl));
-            bestt = __builtin_amdgcn_readlane(bestt, wl);
-            bDL = readlane64(bDL, wl);
-            bDM = readlane64(bDM, wl);
+        }
+        __syncthreads();
+        // ---- phase 3: per-block results, the overall first minimum, its codeword -------------------------
+        u64 mine = ~0ull;
+        for (int b = tid; b < nblk; b += 256) {
+            const u64 k = L.keys[b];
+            const bool empty = k == ~0ull;
+            block_min[f * nblk + b] = empty ? INFINITY : __int_as_float((int)(k >> 32));
+            if (block_arg) block_arg[f * nblk + b] = empty ? -1 : (int)(unsigned)k;
+            mine = k < mine ? k : mine;
+        }
+        if (mine != ~0ull) atomicMin(&L.best, mine);
+        __syncthreads();
+        if (wave == 0) {
+            const u64 k = L.best;
+            const bool none = k == ~0ull;
             if (lane == 0) {
-                block_min[f * nblk + b] = best;
-                if (block_arg) block_arg[f * nblk + b] = t1 > t0 ? bestt : -1;
+                if (metric_out) metric_out[f] = none ? INFINITY : __int_as_float((int)(k >> 32));
+                if (best_out) best_out[f] = none ? -1 : (int)(unsigned)k;
             }
-            if (best < gbest) { gbest = best; gidx = bestt; gDL = bDL; gDM = bDM; }   // blocks ascend: first minimum
+            if (cw_out) {
+                u64 DL = DL0, DM = DM0;
+                if (!none) hosd_apply(L, teps[(unsigned)k], DL, DM);
+                const u64 bitsL = DL ^ L.hgL, bitsM = DM ^ L.hgM;
+                const int o1 = L.o[lane], o2 = L.o[64 + lane];
+                if ((bitsL >> lane) & 1) atomicOr(&L.cw[o1 >> 6], 1ull << (o1 & 63));
+                if ((bitsM >> lane) & 1) atomicOr(&L.cw[o2 >> 6], 1ull << (o2 & 63));
+                wave_fence();
+                if (lane < 2) cw_out[f * 2 + lane] = L.cw[lane];
+            }
         }
-        if (lane == 0) {
-            if (metric_out) metric_out[f] = gbest;
-            if (best_out) best_out[f] = gidx == 0x7FFFFFFF ? -1 : gidx;
-        }
-        if (cw_out) {
-            const u64 bitsL = gDL ^ hgL, bitsM = gDM ^ hgM;
-            if ((bitsL >> lane) & 1) atomicOr(&L.cw[o1 >> 6], 1ull << (o1 & 63));
-            if ((bitsM >> lane) & 1) atomicOr(&L.cw[o2 >> 6], 1ull << (o2 & 63));
-            wave_fence();
-            if (lane < 2) cw_out[f * 2 + lane] = L.cw[lane];
-        }
-        wave_fence();
+        __syncthreads();
     }
 }
 
@@ -257,8 +303,9 @@ int ldpc_hosd_search(ldpc_ctx *ctx, const float *d_order_llr, const float *d_met
     if (!ctx->hosd_ok)
         return fail(LDPC_E_UNSUPPORTED, "H-form OSD kernels need n=128, m=k=64; this code is n=%d m=%d k=%d", ctx->code.n,
                     ctx->code.m, ctx->code.k);
+    if (nblk > kHosdMaxBlocks) return fail(LDPC_E_UNSUPPORTED, "ldpc_hosd_search: %d TEP blocks, at most %d", nblk, kHosdMaxBlocks);
     if (F == 0) return LDPC_OK;
-    hipLaunchKernelGGL(hosd_search_kernel, dim3(grid_for(F, 2)), dim3(128), 0, (hipStream_t)stream, d_order_llr, d_metric_llr,
+    hipLaunchKernelGGL(hosd_search_kernel, dim3(grid_for(F, 1)), dim3(256), 0, (hipStream_t)stream, d_order_llr, d_metric_llr,
                        (long long)F, d_lri, d_uidx, reinterpret_cast<const u64 *>(d_M),
                        reinterpret_cast<const uchar4 *>(d_teps), d_block_off, (int)nblk,
                        reinterpret_cast<const u64 *>(d_label_bits), d_block_min, d_block_arg, d_truth,
