@@ -114,24 +114,58 @@ __device__ __forceinline__ void wave_fence()
 // a 1 and the pair is recorded (:251-256); then column i is cleared in every other row (:258-262).
 // Returns the number of column exchanges, or -1 for a rank-deficient matrix.
 // ---------------------------------------------------------------------------------------
+// (pieces pinned with inline asm: left to itself the compiler moves the pivot column into VGPRs and
+//  spends ~30 VALU instructions per step, most of them in the 4-cycle class; this form needs ~12)
+__device__ __forceinline__ u64 ge_clear_bit(u64 cj, int pr)
+{
+    u64 e;   // cj & ~(1 << pr) on the scalar unit
+    asm("s_lshl_b64 %0, 1, %2\n\ts_andn2_b64 %0, %1, %0" : "=&s"(e) : "s"(cj), "s"(pr) : "scc");
+    return e;
+}
+
+__device__ __forceinline__ u64 ge_sign_ballot(unsigned hi)
+{
+    u64 b;   // lanes whose word has bit 31 set (the compiler would widen this to a 64-bit compare)
+    asm("v_cmp_gt_i32_e64 %0, 0, %1" : "=s"(b) : "v"(hi));
+    return b;
+}
+
+__device__ __forceinline__ int ge_sign_mask(u64 c, int nshift)
+{
+    // -1 where bit (63 - nshift) of c is set: a 64-bit shift and an arithmetic shift, no scalar work
+    // (selecting the 32-bit half with a wave-uniform branch costs ~7 scalar instructions, and the
+    //  scalar unit issues only one instruction per 4 cycles per SIMD, like the vector unit)
+    int m;
+    const unsigned hi = (unsigned)((c << nshift) >> 32);
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m) : "v"(hi));
+    return m;
+}
+
+__device__ __forceinline__ unsigned ge_xor_masked(unsigned c, int m, unsigned e)
+{
+    asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x78" : "+v"(c) : "v"(m), "s"(e));   // c ^ (m & e)
+    return c;
+}
+
 __device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1, int &idx2, int lane,
                                           unsigned char *swaps /* LDS or global [64][2], may be null */)
 {
     int nsw = 0;
-    u64 ge_i = ~0ull;   // lanes (logical rows) >= i
-    for (unsigned i = 0; i < (unsigned)kOsdK; ++i, ge_i <<= 1) {
+    bool deficient = false;   // (no early exit from the loop: it would make the compiler guard every step)
+    int nrho = 63 - rho;   // the loop carries 63 - rho: "bit rho of cj" is then the sign of cj << nrho
+    u64 ge_i = ~0ull;      // lanes (logical rows) >= i
+    for (int i = 0; i < kOsdK; ++i, ge_i <<= 1) {
         u64 cj = readlane64(C1, i);
-        const u64 bal = __ballot((cj >> rho) & 1) & ge_i;
-        unsigned r;
+        u64 bal = ge_sign_ballot((unsigned)((cj << nrho) >> 32)) & ge_i;
         if (bal == 0) {
-            const int pri = __builtin_amdgcn_readlane(rho, i);
+            const int pri = 63 - __builtin_amdgcn_readlane(nrho, i);
             const u64 b1 = __ballot((C1 >> pri) & 1) & ge_i;
             unsigned col;
             if (b1) col = __builtin_ctzll(b1);
             else {
                 const u64 b2 = __ballot((C2 >> pri) & 1);
-                if (b2 == 0) return -1;
-                col = 64 + __builtin_ctzll(b2);
+                deficient |= b2 == 0;   // all-zero row: carry on with garbage, report at the end
+                col = 64 + (b2 ? __builtin_ctzll(b2) : 0);
             }
             // (select form on purpose: branching on col < 64 makes the compiler spill C1/C2 to scratch)
             const unsigned cl = col & 63;
@@ -146,35 +180,35 @@ __device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1,
             idx1 = (hit && lo) ? ii : idx1;
             C2 = (hit && !lo) ? cj : C2;
             idx2 = (hit && !lo) ? ii : idx2;
-            C1 = ((unsigned)lane == i) ? cc : C1;
-            idx1 = ((unsigned)lane == i) ? ic : idx1;
+            C1 = (lane == i) ? cc : C1;
+            idx1 = (lane == i) ? ic : idx1;
             if (swaps && lane == 0) { swaps[2 * nsw] = (unsigned char)i; swaps[2 * nsw + 1] = (unsigned char)col; }
             ++nsw;
-            cj = readlane64(C1, i);   // re-read instead of carrying `cc`: keeps the pivot column in SGPRs on both paths
-            r = i;
-        } else {
-            r = __builtin_ctzll(bal);
+            cj = readlane64(C1, i);   // the exchanged-in column has its 1 in logical row i
+            bal = 1ull << i;
         }
-        const int pr = __builtin_amdgcn_readlane(rho, r);
+        const int r = __builtin_ctzll(bal);
+        const int npr = __builtin_amdgcn_readlane(nrho, r);
         if (r != i) {   // exchange logical rows i and r: two lanes of the row map, no data moves
-            const int pi = __builtin_amdgcn_readlane(rho, i);
+            const int npi = __builtin_amdgcn_readlane(nrho, i);
             // (lane select through M0: a VALU instruction may read only one SGPR on gfx9)
-            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(rho) : "s"(pr), "s"(i) : "m0");
-            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(rho) : "s"(pi), "s"(r) : "m0");
+            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(nrho) : "s"(npr), "s"(i) : "m0");
+            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(nrho) : "s"(npi), "s"(r) : "m0");
         }
-        const u64 e = cj & ~(1ull << pr);
+        const int pr = 63 - npr;
+        const u64 e = ge_clear_bit(cj, pr);
         if (e != 0) {   // nothing to clear when the pivot column is already a unit vector (common: G = [P | I])
-            const unsigned bit = 1u << (pr & 31);
-            if (pr < 32) {   // wave-uniform: test the half that holds physical row pr without a 64-bit shift
-                if ((unsigned)C1 & bit) C1 ^= e;
-                if ((unsigned)C2 & bit) C2 ^= e;
-            } else {
-                if ((unsigned)(C1 >> 32) & bit) C1 ^= e;
-                if ((unsigned)(C2 >> 32) & bit) C2 ^= e;
-            }
+            const unsigned el = (unsigned)e, eh = (unsigned)(e >> 32);
+            unsigned c1l = (unsigned)C1, c1h = (unsigned)(C1 >> 32), c2l = (unsigned)C2, c2h = (unsigned)(C2 >> 32);
+            const int m1 = ge_sign_mask(C1, npr), m2 = ge_sign_mask(C2, npr);
+            c1l = ge_xor_masked(c1l, m1, el); c1h = ge_xor_masked(c1h, m1, eh);
+            c2l = ge_xor_masked(c2l, m2, el); c2h = ge_xor_masked(c2h, m2, eh);
+            C1 = ((u64)c1h << 32) | c1l;
+            C2 = ((u64)c2h << 32) | c2l;
         }
     }
-    return nsw;
+    rho = 63 - nrho;
+    return deficient ? -1 : nsw;
 }
 
 // r += (k > a) as v_cmp_gt_i32 + v_addc through VCC (both 4-byte encodings)
