@@ -269,8 +269,8 @@ def main():
                            "algorithmic_bytes_per_launch": float(nbytes),
                            "all_kernels_ms": {k: v[0] for k, v in kern.items()},
                            "all_kernels_GBps": {k: v[1] / (v[0] * 1e-3) / 1e9 for k, v in kern.items()},
-                           "note": "no contraction on this path (no MFMA); NMS and the OSD front end are VALU-issue bound, "
-                                   "the order-2 scan VALU (88 % busy) and LDS (78 % busy) bound -- see DESIGN.md 5; HBM fraction reported as mandated"}
+                           "note": "no contraction on this path (no MFMA); NMS and the OSD front end are instruction-issue bound "
+                                   "(VALU 100 % / 90 % busy), the order-2 scan latency bound at 2.7 waves/SIMD -- see DESIGN.md 5; HBM fraction reported as mandated"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(dec.code.G, dec.code.H, order)
         print(json.dumps(res), flush=True)
