@@ -247,11 +247,14 @@ __device__ __forceinline__ void check_row(float (&cv)[32], const float (&tot)[8]
     unsigned sx = __float_as_uint(vc[0]) ^ __float_as_uint(vc[1]);
 #pragma unroll
     for (int t = 2; t < 8; ++t) sx ^= __float_as_uint(vc[t]);
-    // cv = (alpha * mag) * S * sign(vc): the product's sign bit is (parity of all signs) ^ (own sign)
+    // cv = alpha * mag * (parity of all signs) * sign(vc): the row parity is folded into the scale factor once
+    // per check (a float product by -alpha is the negated product by alpha, bit for bit), which leaves one
+    // multiply and one "x ^ (vc & sign bit)" per edge instead of multiply + XOR + sign insert
+    const float arow = __uint_as_float(__float_as_uint(aeff) ^ (sx & signv));
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const float mag = aeff * o[t];
-        cv[BR * 8 + t] = __uint_as_float(__float_as_uint(mag) ^ ((sx ^ __float_as_uint(vc[t])) & signv));
+        const float mag = arow * o[t];
+        cv[BR * 8 + t] = __uint_as_float(__float_as_uint(mag) ^ (__float_as_uint(vc[t]) & signv));
     }
 }
 
