@@ -31,6 +31,12 @@ KERNEL(k_lshl_add, "v_lshl_add_u32 %0, %0, 2, %16\n v_lshl_add_u32 %1, %1, 2, %1
 KERNEL(k_bitop3_sgpr, "v_bitop3_b32 %0, %0, %16, %12 bitop3:0x78\n v_bitop3_b32 %1, %1, %16, %12 bitop3:0x78\n v_bitop3_b32 %2, %2, %16, %12 bitop3:0x78\n v_bitop3_b32 %3, %3, %16, %12 bitop3:0x78\n v_bitop3_b32 %4, %4, %16, %12 bitop3:0x78\n v_bitop3_b32 %5, %5, %16, %12 bitop3:0x78\n v_bitop3_b32 %6, %6, %16, %12 bitop3:0x78\n v_bitop3_b32 %7, %7, %16, %12 bitop3:0x78\n")
 KERNEL(k_bitop3_v, "v_bitop3_b32 %0, %0, %16, %1 bitop3:0x78\n v_bitop3_b32 %1, %1, %16, %2 bitop3:0x78\n v_bitop3_b32 %2, %2, %16, %3 bitop3:0x78\n v_bitop3_b32 %3, %3, %16, %4 bitop3:0x78\n v_bitop3_b32 %4, %4, %16, %5 bitop3:0x78\n v_bitop3_b32 %5, %5, %16, %6 bitop3:0x78\n v_bitop3_b32 %6, %6, %16, %7 bitop3:0x78\n v_bitop3_b32 %7, %7, %16, %0 bitop3:0x78\n")
 KERNEL(k_cmp_i32_e64, "v_cmp_gt_i32_e64 vcc, 0, %0\n v_cmp_gt_i32_e64 vcc, 0, %1\n v_cmp_gt_i32_e64 vcc, 0, %2\n v_cmp_gt_i32_e64 vcc, 0, %3\n v_cmp_gt_i32_e64 vcc, 0, %4\n v_cmp_gt_i32_e64 vcc, 0, %5\n v_cmp_gt_i32_e64 vcc, 0, %6\n v_cmp_gt_i32_e64 vcc, 0, %7\n")
+KERNEL(k_min_u32, "v_min_u32_e32 %0, %16, %0\n v_min_u32_e32 %1, %16, %1\n v_min_u32_e32 %2, %16, %2\n v_min_u32_e32 %3, %16, %3\n v_min_u32_e32 %4, %16, %4\n v_min_u32_e32 %5, %16, %5\n v_min_u32_e32 %6, %16, %6\n v_min_u32_e32 %7, %16, %7\n")
+KERNEL(k_min3_u32, "v_min3_u32 %0, %0, %16, %1\n v_min3_u32 %1, %1, %16, %2\n v_min3_u32 %2, %2, %16, %3\n v_min3_u32 %3, %3, %16, %4\n v_min3_u32 %4, %4, %16, %5\n v_min3_u32 %5, %5, %16, %6\n v_min3_u32 %6, %6, %16, %7\n v_min3_u32 %7, %7, %16, %0\n")
+KERNEL(k_min3_i32, "v_min3_i32 %0, %0, %16, %1\n v_min3_i32 %1, %1, %16, %2\n v_min3_i32 %2, %2, %16, %3\n v_min3_i32 %3, %3, %16, %4\n v_min3_i32 %4, %4, %16, %5\n v_min3_i32 %5, %5, %16, %6\n v_min3_i32 %6, %6, %16, %7\n v_min3_i32 %7, %7, %16, %0\n")
+KERNEL(k_min_i16pk, "v_pk_min_u16 %0, %0, %16\n v_pk_min_u16 %1, %1, %16\n v_pk_min_u16 %2, %2, %16\n v_pk_min_u16 %3, %3, %16\n v_pk_min_u16 %4, %4, %16\n v_pk_min_u16 %5, %5, %16\n v_pk_min_u16 %6, %6, %16\n v_pk_min_u16 %7, %7, %16\n")
+KERNEL(k_sub_co_addc, "v_sub_co_u32_e32 %0, vcc, %16, %0\n v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n v_sub_co_u32_e32 %2, vcc, %16, %2\n v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n v_sub_co_u32_e32 %4, vcc, %16, %4\n v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n v_sub_co_u32_e32 %6, vcc, %16, %6\n v_addc_co_u32_e32 %7, vcc, 0, %7, vcc\n")
+KERNEL(k_cmp_addc, "v_cmp_gt_i32_e32 vcc, %16, %0\n v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n v_cmp_gt_i32_e32 vcc, %16, %2\n v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n v_cmp_gt_i32_e32 vcc, %16, %4\n v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n v_cmp_gt_i32_e32 vcc, %16, %6\n v_addc_co_u32_e32 %7, vcc, 0, %7, vcc\n")
 KERNEL(k_salu, "s_add_u32 %12, %12, %17\n s_add_u32 %13, %13, %17\n s_add_u32 %14, %14, %17\n s_add_u32 %15, %15, %17\n s_lshl_b32 %12, %12, 1\n s_lshl_b32 %13, %13, 1\n s_lshl_b32 %14, %14, 1\n s_lshl_b32 %15, %15, 1\n")
 KERNEL(k_salu_dep, "s_add_u32 %12, %12, %17\n s_lshl_b32 %12, %12, 1\n s_add_u32 %12, %12, %17\n s_lshl_b32 %12, %12, 1\n s_add_u32 %12, %12, %17\n s_lshl_b32 %12, %12, 1\n s_add_u32 %12, %12, %17\n s_lshl_b32 %12, %12, 1\n")
 KERNEL(k_readlane_dep, "v_readlane_b32 %12, %0, %17\n s_and_b32 %12, %12, 63\n v_readlane_b32 %13, %1, %12\n s_and_b32 %13, %13, 63\n v_readlane_b32 %12, %2, %13\n s_and_b32 %12, %12, 63\n v_readlane_b32 %13, %3, %12\n s_and_b32 %13, %13, 63\n")
@@ -77,6 +83,12 @@ int main()
     run("v_bitop3_b32 sgpr", k_bitop3_sgpr, d, 8);
     run("v_bitop3_b32 vgpr", k_bitop3_v, d, 8);
     run("v_cmp_gt_i32_e64", k_cmp_i32_e64, d, 8);
+    run("v_min_u32_e32", k_min_u32, d, 8);
+    run("v_min3_u32", k_min3_u32, d, 8);
+    run("v_min3_i32", k_min3_i32, d, 8);
+    run("v_pk_min_u16", k_min_i16pk, d, 8);
+    run("v_sub_co + v_addc", k_sub_co_addc, d, 8);
+    run("v_cmp_gt_i32 + v_addc", k_cmp_addc, d, 8);
     run("salu independent", k_salu, d, 8);
     run("salu dependent chain", k_salu_dep, d, 8);
     run("readlane->salu->readlane", k_readlane_dep, d, 8);

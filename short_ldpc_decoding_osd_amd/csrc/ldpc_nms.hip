@@ -244,9 +244,11 @@ __device__ __forceinline__ void check_row(float (&cv)[32], const float (&tot)[8]
     o[5] = __builtin_fminf(__builtin_fminf(a[4], p67), q03);
     o[6] = __builtin_fminf(__builtin_fminf(a[7], p45), q03);
     o[7] = __builtin_fminf(__builtin_fminf(a[6], p45), q03);
-    unsigned sx = __float_as_uint(vc[0]) ^ __float_as_uint(vc[1]);
-#pragma unroll
-    for (int t = 2; t < 8; ++t) sx ^= __float_as_uint(vc[t]);
+    // parity of the eight sign bits: three 3-input XORs (v_bitop3_b32 0x96) and one 2-input instead of seven XORs
+    const unsigned x012 = __builtin_amdgcn_bitop3_b32(__float_as_uint(vc[0]), __float_as_uint(vc[1]), __float_as_uint(vc[2]), 0x96);
+    const unsigned x345 = __builtin_amdgcn_bitop3_b32(__float_as_uint(vc[3]), __float_as_uint(vc[4]), __float_as_uint(vc[5]), 0x96);
+    const unsigned x67 = __float_as_uint(vc[6]) ^ __float_as_uint(vc[7]);
+    const unsigned sx = __builtin_amdgcn_bitop3_b32(x012, x345, x67, 0x96);
     // cv = alpha * mag * (parity of all signs) * sign(vc): the row parity is folded into the scale factor once
     // per check (a float product by -alpha is the negated product by alpha, bit for bit), which leaves one
     // multiply and one "x ^ (vc & sign bit)" per edge instead of multiply + XOR + sign insert
