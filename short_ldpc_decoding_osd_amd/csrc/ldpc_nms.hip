@@ -271,7 +271,7 @@ __device__ __forceinline__ int syndrome_row(const int (&h)[8])
 }
 
 template <bool UP>
-__global__ __launch_bounds__(256) void nms_qc16_kernel(const float *__restrict__ llr, long long B, int T,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void nms_qc16_kernel(const float *__restrict__ llr, long long B, int T,
                                                        AlphaArg alpha, float w_in, float w_out,
                                                        float *__restrict__ soft, float *__restrict__ traj,
                                                        unsigned long long *__restrict__ hard,
