@@ -189,7 +189,11 @@ typedef struct ldpc_osd_params {
  *                         (conventional), or its rank in visit order (FS/PB; 0 = all-zero TEP)
  *   d_ntep    [F] i32     number of TEPs evaluated (FS: num_teps, fs_testing.py:141; PB: cost_tep_num
  *                         or N_max when no rule fired, pb_testing.py:152-155)
- * Any of d_metric/d_best/d_ntep may be NULL.                                              */
+ * Any of d_metric/d_best/d_ntep may be NULL.
+ * Concurrency: conventional and FS calls on different streams may overlap (with caller-supplied
+ * d_perm/d_parity through ldpc_osd_search / ldpc_pipeline_run; ldpc_osd_decode itself uses the context's
+ * one workspace).  PB-OSD calls share the context's frontier spill area and frame counter: do not
+ * overlap two of them on one context -- create one context per stream.                       */
 int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
                     const ldpc_osd_params *params, uint64_t *d_cw, float *d_metric, int32_t *d_best,
                     int32_t *d_ntep, void *stream);
