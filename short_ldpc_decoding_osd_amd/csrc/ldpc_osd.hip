@@ -511,22 +511,28 @@ __global__ __launch_bounds__(256) void osd_fs_kernel(const float *__restrict__ y
                     u64 D = 0, E = 0;
                     float mrb = 0.0f;
                     if (valid) tep_apply(L, tab[t], S.d0, D, E, mrb);
-                    const float c = tep_cost(L, mrb, D);
                     const float hd = (float)(w + __popcll(D));
                     const u64 stop = __ballot(valid && hd < P.tau_e);
                     const int lim = stop ? __builtin_ctzll(stop) : 64;
                     const int nvalid = (cnt - t0) < 64 ? (cnt - t0) : 64;
                     ntep += stop ? lim + 1 : nvalid;
-                    // best among the TEPs visited before the stop that pass the tau_psc rule
-                    float cc = (valid && lane < lim && hd < P.tau_psc) ? c : __builtin_inff();
-                    int ci = lane;
-                    u64 cD = D, cE = E;
-                    wave_argmin(cc, ci, cD, cE, lane);
-                    if (cc < best) { best = cc; bestD = cD; bestE = cE; bestidx = visited + t0 + ci; }
+                    // best among the TEPs visited before the stop that pass the tau_psc rule: the metric is only
+                    // needed for those, and only if it can beat `best` (exact prefix early exit, tep_cost_bounded)
+                    float cc = __builtin_inff();
+                    if (valid && lane < lim && hd < P.tau_psc) {
+                        float c;
+                        if (tep_cost_bounded(L, mrb, D, best, c)) cc = c;
+                    }
+                    if (__ballot(cc < best)) {
+                        int ci = lane;
+                        u64 cD = D, cE = E;
+                        wave_argmin(cc, ci, cD, cE, lane);
+                        best = cc; bestD = cD; bestE = cE; bestidx = visited + t0 + ci;
+                    }
                     if (stop) {
                         hit = true;
                         hitD = readlane64(D, lim); hitE = readlane64(E, lim);
-                        hitc = __shfl(c, lim, 64);
+                        hitc = tep_cost(L, __shfl(mrb, lim, 64), hitD);   // the stopping candidate's own metric
                         hitidx = visited + t0 + lim;
                     }
                 }
