@@ -185,7 +185,7 @@ __device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1,
             if (swaps && lane == 0) { swaps[2 * nsw] = (unsigned char)i; swaps[2 * nsw + 1] = (unsigned char)col; }
             ++nsw;
             cj = readlane64(C1, i);   // the exchanged-in column has its 1 in logical row i
-            bal = 1ull << i;
+            bal = ge_i & (0ull - ge_i);   // = 1 << i (keeps the loop counter 32 bits wide)
         }
         const int r = __builtin_ctzll(bal);
         const int npr = __builtin_amdgcn_readlane(nrho, r);
