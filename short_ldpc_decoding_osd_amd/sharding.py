@@ -29,7 +29,7 @@ def allreduce_counters(counters: torch.Tensor) -> torch.Tensor:
 
     if counters.dtype != torch.int64:
         raise ValueError("counters must be int64")
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
     return counters
 
