@@ -239,22 +239,26 @@ template <int NB>
 __device__ __forceinline__ void build_byte_luts(float (*lut)[256], const float *w, int lane)
 {
     const int lo5 = lane & 31, top = lane >> 5;
+    // the lane's index bits as 0.0f / 1.0f factors: "add w if the bit is set" becomes one fma (exact: the
+    // product by 0 or 1 is exact and the fma rounds once, like the add) instead of a select plus an add --
+    // v_cndmask issues at half the rate of v_fma on gfx950.  (Weights are finite magnitudes.)
+    const float b0 = (lo5 & 1) ? 1.0f : 0.0f, b1 = (lo5 & 2) ? 1.0f : 0.0f, b2 = (lo5 & 4) ? 1.0f : 0.0f;
+    const float b3 = (lo5 & 8) ? 1.0f : 0.0f, b4 = (lo5 & 16) ? 1.0f : 0.0f, b7 = top ? 1.0f : 0.0f;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const float4 wa = *reinterpret_cast<const float4 *>(&w[8 * b]);       // broadcast reads
         const float4 wb = *reinterpret_cast<const float4 *>(&w[8 * b + 4]);
-        float base = 0.0f;
-        base = base + ((lo5 & 1) ? wa.x : 0.0f);
-        base = base + ((lo5 & 2) ? wa.y : 0.0f);
-        base = base + ((lo5 & 4) ? wa.z : 0.0f);
-        base = base + ((lo5 & 8) ? wa.w : 0.0f);
-        base = base + ((lo5 & 16) ? wb.x : 0.0f);
-        const float h7 = top ? wb.w : 0.0f;
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {   // index bits 5, 6 = h, bit 7 = top
-            const float v5 = (h & 1) ? wb.y : 0.0f, v6 = (h & 2) ? wb.z : 0.0f;
-            lut[b][(top * 4 + h) * 32 + lo5] = ((base + v5) + v6) + h7;
-        }
+        float base = wa.x * b0;
+        base = __builtin_fmaf(wa.y, b1, base);
+        base = __builtin_fmaf(wa.z, b2, base);
+        base = __builtin_fmaf(wa.w, b3, base);
+        base = __builtin_fmaf(wb.x, b4, base);
+        const float h7 = wb.w * b7;
+        // index bits 5, 6 = h, bit 7 = top; sums stay in ascending position order
+        lut[b][(top * 4 + 0) * 32 + lo5] = base + h7;
+        lut[b][(top * 4 + 1) * 32 + lo5] = (base + wb.y) + h7;
+        lut[b][(top * 4 + 2) * 32 + lo5] = (base + wb.z) + h7;
+        lut[b][(top * 4 + 3) * 32 + lo5] = ((base + wb.y) + wb.z) + h7;
     }
 }
 
