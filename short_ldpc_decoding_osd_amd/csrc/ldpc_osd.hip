@@ -694,6 +694,8 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
         }
         wave_fence();
         int nused = 1, nlive = 1, ntep = P.nmax, bestidx = 0, stop = 0, cmp = 0, suc1 = 0, suc2 = 0;
+        int tail_ck = 0, tail_ci = 0, tail_sk = 0, tail_si = 0;   // last chunk / super-chunk of the list and their minima
+        float tail_cs = L.w[63], tail_ss = L.w[63];
         float best = tep_cost(L, 0.0f, S.d0);
         u64 bestD = S.d0, bestE = 0;
         const PbList FL{&B, spill, P.cmin_off};
@@ -745,35 +747,54 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
             }
             nused += (has1 ? 1 : 0) + (has2 ? 1 : 0);
             nlive += (has1 ? 1 : 0) + (has2 ? 1 : 0) - 1;
-            __threadfence_block();
-            wave_fence();
-            // refresh the minima: the popped slot's chunk and every chunk that received a child are re-reduced,
-            // then the super-chunks above them (at most two chunks and two super-chunks are touched)
-            const int ck0 = mi >> 6, ck1 = has1 ? (s1 >> 6) : ck0, ck2 = has2 ? (s2 >> 6) : ck0;
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int ck = u == 0 ? ck0 : (u == 1 ? ck1 : ck2);
-                if ((u == 1 && ck1 == ck0) || (u == 2 && (ck2 == ck0 || ck2 == ck1))) continue;
-                const int t = ck * 64 + lane;
+            wave_fence();   // (the list is private to the wavefront: wavefront scope orders its own loads after its stores)
+            // refresh the minima.  Only the popped slot's chunk (and its super-chunk) needs a re-reduction; the
+            // children are appended at the tail of the list, so the minimum of the chunk / super-chunk they land
+            // in changes only if the child is smaller (on a tie the older, lower slot stays the first minimum) --
+            // tracked in wave-uniform registers, written through, never read back from (global) memory
+            const int ck0 = mi >> 6, sk0 = ck0 >> 6;
+            {
+                const int t = ck0 * 64 + lane;
                 float cs = __builtin_inff();
                 int ci = 0x7FFFFFFF;
                 if (t < nused) { cs = FL.slot(t).sum; ci = t; }
                 argmin_si(cs, ci, lane);
-                if (lane == 0) { PbEntry m; m.sum = cs; m.pos = (unsigned)ci; FL.set_cmin(ck, m); }
+                if (lane == 0) { PbEntry m; m.sum = cs; m.pos = (unsigned)ci; FL.set_cmin(ck0, m); }
+                if (ck0 == tail_ck) { tail_cs = cs; tail_ci = ci; }
             }
-            __threadfence_block();
-            wave_fence();
-            const int sk0 = ck0 >> 6, sk1 = ck1 >> 6, sk2 = ck2 >> 6;
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int sk = u == 0 ? sk0 : (u == 1 ? sk1 : sk2);
-                if ((u == 1 && sk1 == sk0) || (u == 2 && (sk2 == sk0 || sk2 == sk1))) continue;
-                const int c = sk * 64 + lane;
+            for (int u = 0; u < 2; ++u) {
+                const bool has = u == 0 ? has1 : has2;
+                const int sl = u == 0 ? s1 : s2;
+                const float csum = u == 0 ? c1.sum : c2.sum;
+                if (!has) continue;
+                const int ck = sl >> 6;
+                if (ck != tail_ck) { tail_ck = ck; tail_cs = __builtin_inff(); tail_ci = 0x7FFFFFFF; }   // a new chunk starts
+                if (ck == ck0) continue;                                   // covered by the re-reduction above
+                if (csum < tail_cs) { tail_cs = csum; tail_ci = sl; }
+                if (lane == 0) { PbEntry m; m.sum = tail_cs; m.pos = (unsigned)tail_ci; FL.set_cmin(ck, m); }
+            }
+            wave_fence();   // (the list is private to the wavefront: wavefront scope orders its own loads after its stores)
+            {
+                const int c = sk0 * 64 + lane;
                 float cs = __builtin_inff();
                 int ci = 0x7FFFFFFF;
                 if (c * 64 < nused) { const PbEntry m = FL.cmin(c); cs = m.sum; ci = (int)m.pos; }
                 argmin_si(cs, ci, lane);
-                if (lane == 0) { PbEntry m; m.sum = cs; m.pos = (unsigned)ci; B.smin[sk] = m; }
+                if (lane == 0) { PbEntry m; m.sum = cs; m.pos = (unsigned)ci; B.smin[sk0] = m; }
+                if (sk0 == tail_sk) { tail_ss = cs; tail_si = ci; }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool has = u == 0 ? has1 : has2;
+                const int sl = u == 0 ? s1 : s2;
+                const float csum = u == 0 ? c1.sum : c2.sum;
+                if (!has) continue;
+                const int sk = sl >> 12;
+                if (sk != tail_sk) { tail_sk = sk; tail_ss = __builtin_inff(); tail_si = 0x7FFFFFFF; }
+                if (sk == sk0) continue;
+                if (csum < tail_ss) { tail_ss = csum; tail_si = sl; }
+                if (lane == 0) { PbEntry m; m.sum = tail_ss; m.pos = (unsigned)tail_si; B.smin[sk] = m; }
             }
             wave_fence();
             // promising-probability rule
