@@ -591,6 +591,7 @@ constexpr int kPbLdsSlots = 512, kPbLdsChunks = 64, kPbSuper = 32;   // 32 super
 
 struct __attribute__((aligned(16))) PbLds {
     double cdfA[65];             // P[Bin(64, p1) <= b]
+    double cdfH[65];             // P[Bin(64, 1/2) <= b] (copied once per wavefront: a global read per TEP sat on the critical path)
     float q[128];                // sigmoid(c4 |y'_p|)
     PbEntry fr[kPbLdsSlots];     // head of the list
     PbEntry cmin[kPbLdsChunks];  // chunk minima of the first 4096 slots
@@ -642,6 +643,9 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
     if (count) { const long long c = *count; nframes = c < F ? c : F; }
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     PbEntry *spill = spill_all + wave * spill_stride;
+    B.cdfH[lane] = cdf_half[lane];
+    if (lane == 0) B.cdfH[64] = cdf_half[64];
+    wave_fence();
 
     // frames are handed out through a device counter: PB-OSD run times differ by orders of magnitude between
     // frames (a frame on which no rule fires visits all N_max TEPs), a static assignment would wait for the
@@ -707,7 +711,19 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
             if (lane < nsuper) { const PbEntry t = B.smin[lane]; ms = t.sum; mi = (int)t.pos; }
             argmin_si(ms, mi, lane);
             cmp += nlive == 1 ? 1 : 2;
-            const PbEntry e = FL.slot(mi);
+            // Both levels of the list that this pop touches are loaded NOW, side by side: the 64 slots of the
+            // popped slot's chunk (lane mi & 63 of it is the popped entry itself) and the 64 chunk minima of its
+            // super-chunk.  Everything that changes below (the tombstone, children that land in the same chunk,
+            // the new chunk minimum) is patched into these registers, so one round trip to the spilled part of the
+            // list (global memory) is on the critical path of a TEP instead of three dependent ones.
+            const int ck0 = mi >> 6, sk0 = ck0 >> 6;
+            PbEntry mys, myc;
+            mys.sum = myc.sum = __builtin_inff(); mys.pos = 0; myc.pos = 0x7FFFFFFFu;
+            if (ck0 * 64 + lane < nused) mys = FL.slot(ck0 * 64 + lane);
+            if ((sk0 * 64 + lane) * 64 < nused) myc = FL.cmin(sk0 * 64 + lane);
+            PbEntry e;
+            e.sum = ms;
+            e.pos = (unsigned)__builtin_amdgcn_readlane((int)mys.pos, mi & 63);
             const int ew = (int)(e.pos >> 24);
             const int p0 = e.pos & 0xFF, pA = (e.pos >> 8) & 0xFF, pB = (e.pos >> 16) & 0xFF;
             const int last = ew == 1 ? p0 : (ew == 2 ? pA : pB);
@@ -737,7 +753,6 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
             }
             if (has2 && !has1) { c1 = c2; has1 = true; has2 = false; }      // children in list order: c1 then c2
             const int s1 = nused, s2 = nused + 1;
-            wave_fence();
             if (lane == 0) {
                 PbEntry dead;
                 dead.sum = __builtin_inff(); dead.pos = 0;
@@ -747,21 +762,17 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
             }
             nused += (has1 ? 1 : 0) + (has2 ? 1 : 0);
             nlive += (has1 ? 1 : 0) + (has2 ? 1 : 0) - 1;
-            wave_fence();   // (the list is private to the wavefront: wavefront scope orders its own loads after its stores)
-            // refresh the minima.  Only the popped slot's chunk (and its super-chunk) needs a re-reduction; the
-            // children are appended at the tail of the list, so the minimum of the chunk / super-chunk they land
-            // in changes only if the child is smaller (on a tie the older, lower slot stays the first minimum) --
-            // tracked in wave-uniform registers, written through, never read back from (global) memory
-            const int ck0 = mi >> 6, sk0 = ck0 >> 6;
-            {
-                const int t = ck0 * 64 + lane;
-                float cs = __builtin_inff();
-                int ci = 0x7FFFFFFF;
-                if (t < nused) { cs = FL.slot(t).sum; ci = t; }
-                argmin_si(cs, ci, lane);
-                if (lane == 0) { PbEntry m; m.sum = cs; m.pos = (unsigned)ci; FL.set_cmin(ck0, m); }
-                if (ck0 == tail_ck) { tail_cs = cs; tail_ci = ci; }
-            }
+            // ---- chunk level: the popped slot's chunk from the patched registers; the tail chunk incrementally
+            if (lane == (mi & 63)) mys.sum = __builtin_inff();
+            if (has1 && (s1 >> 6) == ck0 && lane == (s1 & 63)) mys = c1;
+            if (has2 && (s2 >> 6) == ck0 && lane == (s2 & 63)) mys = c2;
+            float cs0 = mys.sum;
+            int ci0 = ck0 * 64 + lane;
+            argmin_si(cs0, ci0, lane);
+            if (lane == 0) { PbEntry m; m.sum = cs0; m.pos = (unsigned)ci0; FL.set_cmin(ck0, m); }
+            if (ck0 == tail_ck) { tail_cs = cs0; tail_ci = ci0; }
+            // ---- super-chunk level, same scheme on the chunk minima (patched as the chunk level changes them)
+            if (lane == (ck0 & 63)) { myc.sum = cs0; myc.pos = (unsigned)ci0; }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const bool has = u == 0 ? has1 : has2;
@@ -770,20 +781,16 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
                 if (!has) continue;
                 const int ck = sl >> 6;
                 if (ck != tail_ck) { tail_ck = ck; tail_cs = __builtin_inff(); tail_ci = 0x7FFFFFFF; }   // a new chunk starts
-                if (ck == ck0) continue;                                   // covered by the re-reduction above
-                if (csum < tail_cs) { tail_cs = csum; tail_ci = sl; }
+                if (ck == ck0) continue;                                   // covered by the reduction above
+                if (csum < tail_cs) { tail_cs = csum; tail_ci = sl; }      // (a tie keeps the older, lower slot)
                 if (lane == 0) { PbEntry m; m.sum = tail_cs; m.pos = (unsigned)tail_ci; FL.set_cmin(ck, m); }
+                if ((ck >> 6) == sk0 && lane == (ck & 63)) { myc.sum = tail_cs; myc.pos = (unsigned)tail_ci; }
             }
-            wave_fence();   // (the list is private to the wavefront: wavefront scope orders its own loads after its stores)
-            {
-                const int c = sk0 * 64 + lane;
-                float cs = __builtin_inff();
-                int ci = 0x7FFFFFFF;
-                if (c * 64 < nused) { const PbEntry m = FL.cmin(c); cs = m.sum; ci = (int)m.pos; }
-                argmin_si(cs, ci, lane);
-                if (lane == 0) { PbEntry m; m.sum = cs; m.pos = (unsigned)ci; B.smin[sk0] = m; }
-                if (sk0 == tail_sk) { tail_ss = cs; tail_si = ci; }
-            }
+            float ss0 = myc.sum;
+            int si0 = (int)myc.pos;
+            argmin_si(ss0, si0, lane);
+            if (lane == 0) { PbEntry m; m.sum = ss0; m.pos = (unsigned)si0; B.smin[sk0] = m; }
+            if (sk0 == tail_sk) { tail_ss = ss0; tail_si = si0; }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const bool has = u == 0 ? has1 : has2;
@@ -804,7 +811,7 @@ __global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y
             const int beta = bt > 0.0f ? (bt < 64.0f ? (int)bt : 64) : 0;
             float bs = 0.0f;
             bs = bs + w1 * (float)B.cdfA[beta];
-            bs = bs + w2 * (float)cdf_half[beta];
+            bs = bs + w2 * (float)B.cdfH[beta];
             if ((double)bs < p_t_pro) { stop = 1; ntep = j + 1; break; }
             u64 D = S.d0 ^ L.P[p0], E = 1ull << p0;
             if (ew > 1) { D ^= L.P[pA]; E |= 1ull << pA; }
