@@ -279,22 +279,25 @@ __device__ __forceinline__ void wave_argmin(float &best, int &bestt, u64 &bestD,
     bestE = readlane64(bestE, w);
 }
 
-__global__ __launch_bounds__(256) void osd_search_kernel(const float *__restrict__ y, const int *__restrict__ index,
-                                                         const int *__restrict__ count, long long F,
-                                                         const unsigned char *__restrict__ perm_in,
-                                                         const u64 *__restrict__ parity_in,
-                                                         const uchar4 *__restrict__ teps, int ntep,
-                                                         u64 *__restrict__ cw_out, float *__restrict__ metric_out,
-                                                         int *__restrict__ best_out, int *__restrict__ ntep_out)
+// WAVES = 1 for the long scans (one wavefront per workgroup: compile-time LDS base for the LUT reads, frames
+// balanced by the dispatcher), 4 for orders 0 and 1, where a frame is too little work to pay for a workgroup
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void osd_search_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                                const int *__restrict__ count, long long F,
+                                                                const unsigned char *__restrict__ perm_in,
+                                                                const u64 *__restrict__ parity_in,
+                                                                const uchar4 *__restrict__ teps, int ntep,
+                                                                u64 *__restrict__ cw_out, float *__restrict__ metric_out,
+                                                                int *__restrict__ best_out, int *__restrict__ ntep_out)
 {
-    __shared__ SearchLds lds[4];
+    __shared__ SearchLds lds[WAVES];
     const int lane = threadIdx.x & 63;
-    SearchLds &L = lds[threadIdx.x >> 6];
+    SearchLds &L = lds[WAVES == 1 ? 0 : threadIdx.x >> 6];
     long long nframes = F;
     if (count) { const long long c = *count; nframes = c < F ? c : F; }
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long wave = (long long)blockIdx.x * WAVES + (threadIdx.x >> 6);
 
-    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+    for (long long f = wave; f < nframes; f += (long long)gridDim.x * WAVES) {
         const long long src = index ? index[f] : f;
         const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
         // scan the TEP table, one TEP per lane per round; strict '<' keeps the first minimum
@@ -475,22 +478,22 @@ struct FsParams {
     int cls_off[4], cls_cnt[4];   // weight class w: offset / count inside the FS-ordered table
 };
 
-__global__ __launch_bounds__(256) void osd_fs_kernel(const float *__restrict__ y, const int *__restrict__ index,
-                                                     const int *__restrict__ count, long long F,
-                                                     const unsigned char *__restrict__ perm_in,
-                                                     const u64 *__restrict__ parity_in,
-                                                     const uchar4 *__restrict__ teps_fs, FsParams P,
-                                                     u64 *__restrict__ cw_out, float *__restrict__ metric_out,
-                                                     int *__restrict__ best_out, int *__restrict__ ntep_out)
+// (one wavefront per workgroup, as the order-2 scan: compile-time LDS base for the LUT reads, and the
+//  dispatcher balances the very uneven per-frame TEP counts)
+__global__ __launch_bounds__(64) void osd_fs_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                    const int *__restrict__ count, long long F,
+                                                    const unsigned char *__restrict__ perm_in,
+                                                    const u64 *__restrict__ parity_in,
+                                                    const uchar4 *__restrict__ teps_fs, FsParams P,
+                                                    u64 *__restrict__ cw_out, float *__restrict__ metric_out,
+                                                    int *__restrict__ best_out, int *__restrict__ ntep_out)
 {
-    __shared__ SearchLds lds[4];
-    const int lane = threadIdx.x & 63;
-    SearchLds &L = lds[threadIdx.x >> 6];
+    __shared__ SearchLds L;
+    const int lane = threadIdx.x;
     long long nframes = F;
     if (count) { const long long c = *count; nframes = c < F ? c : F; }
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
 
-    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+    for (long long f = blockIdx.x; f < nframes; f += gridDim.x) {
         const long long src = index ? index[f] : f;
         const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
         float best = tep_cost(L, 0.0f, S.d0);      // all-zero TEP (:131)
@@ -1096,16 +1099,21 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
         fp.beta_term = (float)((double)p->fs_beta * (double)(kOsdN - kOsdK));   // fs_testing.py:138
         fp.tau_e = p->fs_tau_e; fp.tau_psc = p->fs_tau_psc;
         for (int w = 0; w < 4; ++w) { fp.cls_off[w] = st->fs_off[w]; fp.cls_cnt[w] = st->fs_cnt[w]; }
-        hipLaunchKernelGGL(osd_fs_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
+        hipLaunchKernelGGL(osd_fs_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
                            d_perm, d_parity, st->d_tep_fs, fp, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
                            d_ntep);
     } else if (p->order == 2 && !p->reserved) {
         hipLaunchKernelGGL(osd_search2_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
                            d_perm, d_parity, st->d_base2, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
     } else {   // table-driven scan: any order (and order 2 when params->reserved = 1, the cross-check path)
-        hipLaunchKernelGGL(osd_search_kernel, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
-                           d_perm, d_parity, reinterpret_cast<const uchar4 *>(ctx->d_tep), (int)st->ntep[p->order],
-                           reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
+        if (p->order >= 2)
+            hipLaunchKernelGGL(osd_search_kernel<1>, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
+                               d_perm, d_parity, reinterpret_cast<const uchar4 *>(ctx->d_tep), (int)st->ntep[p->order],
+                               reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
+        else
+            hipLaunchKernelGGL(osd_search_kernel<4>, dim3(osd_grid(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
+                               d_perm, d_parity, reinterpret_cast<const uchar4 *>(ctx->d_tep), (int)st->ntep[p->order],
+                               reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
     }
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;
