@@ -139,20 +139,18 @@ __device__ __forceinline__ FrontResult front_device(FrontLds &L, const float *__
     return res;
 }
 
-__global__ __launch_bounds__(256) void osd_front_kernel(const float *__restrict__ y, const int *__restrict__ index,
+__global__ __launch_bounds__(64) void osd_front_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                         const int *__restrict__ count, long long F,
                                                         const u64 *__restrict__ Gcols,
                                                         unsigned char *__restrict__ perm_out,
                                                         u64 *__restrict__ parity_out, int *__restrict__ nswaps)
 {
-    __shared__ FrontLds lds[4];
-    const int lane = threadIdx.x & 63;
-    FrontLds &L = lds[threadIdx.x >> 6];
+    __shared__ FrontLds L;   // one wavefront per workgroup
+    const int lane = threadIdx.x;
     long long nframes = F;
     if (count) { const long long c = *count; nframes = c < F ? c : F; }
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
 
-    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+    for (long long f = blockIdx.x; f < nframes; f += gridDim.x) {
         const long long src = index ? index[f] : f;
         const FrontResult res = front_device(L, y, src, Gcols, lane);
         perm_out[f * 128 + lane] = (unsigned char)res.o1;
@@ -1003,14 +1001,6 @@ static unsigned osd_grid(int64_t F)
     return (unsigned)(want < 1 ? 1 : (want < 4096 ? want : 4096));
 }
 
-static unsigned osd_grid_fine(int64_t F)
-{
-    // front end / order-2 scan: one frame per wavefront up to 2^16 frames -- the hardware dispatcher then
-    // balances the uneven per-frame times (measured: 119 -> 116.5 us and 125 -> 117 us); the FS scan is
-    // faster on the coarser grid
-    int64_t want = (F + 3) / 4;
-    return (unsigned)(want < 1 ? 1 : (want < 16384 ? want : 16384));
-}
 
 }  // namespace ldpc
 
@@ -1044,7 +1034,7 @@ int ldpc_osd_front(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, cons
     if (!ctx || F < 0 || (F > 0 && (!d_y || !d_perm || !d_parity))) return fail(LDPC_E_ARG, "ldpc_osd_front: bad arguments");
     if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
     if (F == 0) return LDPC_OK;
-    hipLaunchKernelGGL(osd_front_kernel, dim3(osd_grid_fine(F)), dim3(256), 0, (hipStream_t)stream, d_y, d_index, d_count,
+    hipLaunchKernelGGL(osd_front_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, (hipStream_t)stream, d_y, d_index, d_count,
                        (long long)F, reinterpret_cast<const u64 *>(ctx->d_Gcols), d_perm, reinterpret_cast<u64 *>(d_parity),
                        d_nswaps);
     LDPC_HIP(hipGetLastError());
@@ -1149,7 +1139,7 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
         if (rc) return rc;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(osd_front_kernel, dim3(osd_grid_fine(F)), dim3(256), 0, s, d_y, d_index, d_count, (long long)F,
+    hipLaunchKernelGGL(osd_front_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
                        reinterpret_cast<const u64 *>(ctx->d_Gcols), st->d_perm, st->d_parity, (int *)nullptr);
     return launch_search(ctx, d_y, d_index, d_count, F, st->d_perm, st->d_parity, p, d_cw, d_metric, d_best, d_ntep, s);
 }
