@@ -111,11 +111,13 @@ struct __attribute__((aligned(16))) HSearchLds {
 
 __device__ __forceinline__ float hosd_cost(const HSearchLds &L, u64 DL, u64 DM)
 {
-    float acc = L.lut[0][DL & 0xFF];
-#pragma unroll
-    for (int b = 1; b < 8; ++b) acc = acc + L.lut[b][(DL >> (8 * b)) & 0xFF];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) acc = acc + L.lut[8 + b][(DM >> (8 * b)) & 0xFF];
+    float acc = lut_byte<0>(L.lut, DL);
+    acc = acc + lut_byte<1>(L.lut, DL); acc = acc + lut_byte<2>(L.lut, DL); acc = acc + lut_byte<3>(L.lut, DL);
+    acc = acc + lut_byte<4>(L.lut, DL); acc = acc + lut_byte<5>(L.lut, DL); acc = acc + lut_byte<6>(L.lut, DL);
+    acc = acc + lut_byte<7>(L.lut, DL);
+    acc = acc + lut_byte<0>(&L.lut[8], DM); acc = acc + lut_byte<1>(&L.lut[8], DM); acc = acc + lut_byte<2>(&L.lut[8], DM);
+    acc = acc + lut_byte<3>(&L.lut[8], DM); acc = acc + lut_byte<4>(&L.lut[8], DM); acc = acc + lut_byte<5>(&L.lut[8], DM);
+    acc = acc + lut_byte<6>(&L.lut[8], DM); acc = acc + lut_byte<7>(&L.lut[8], DM);
     return acc;
 }
 

@@ -262,4 +262,18 @@ __device__ __forceinline__ void build_byte_luts(float (*lut)[256], const float *
     }
 }
 
+// lut[B][byte B of D]: the byte is extracted and scaled to a byte offset by ONE SDWA shift (instead of
+// v_bfe + v_lshl_add); with a compile-time LDS base the table offset folds into the ds_read immediate
+template <int B>
+__device__ __forceinline__ float lut_byte(const float (*lut)[256], u64 D)
+{
+    const unsigned word = B < 4 ? (unsigned)D : (unsigned)(D >> 32);
+    unsigned off;
+    if constexpr ((B & 3) == 0) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(word));
+    else if constexpr ((B & 3) == 1) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(word));
+    else if constexpr ((B & 3) == 2) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(word));
+    else asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(word));
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lut[B]) + off);
+}
+
 }  // namespace ldpc
