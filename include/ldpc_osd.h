@@ -258,8 +258,8 @@ int ldpc_hosd_search(ldpc_ctx *ctx, const float *d_order_llr, const float *d_met
  * per-batch loops (ldpc_128_testing.py:117-131 then pb_testing.py / fs_testing.py per failed frame):
  *   NMS-T -> error counters -> failed-frame compaction -> OSD (front end + search) on the failures
  *   -> OSD counters.
- * Exactly the sequence ldpc_nms_decode, ldpc_eval_counts, ldpc_compact, ldpc_osd_front,
- * ldpc_osd_search, ldpc_osd_counts on one stream, without a host round trip in between (the OSD
+ * The results of the sequence ldpc_nms_decode, ldpc_eval_counts, ldpc_compact, ldpc_osd_front,
+ * ldpc_osd_search, ldpc_osd_counts on one stream (the counters ride in the compaction's counting pass), without a host round trip in between (the OSD
  * kernels read the failure count on the device).  Nullable members switch their stage off.
  * With timing_slot >= 0 the library brackets the three hot kernels with its own HIP events on
  * `stream`; after synchronising, ldpc_pipeline_timing returns their durations.

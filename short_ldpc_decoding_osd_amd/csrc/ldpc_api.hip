@@ -115,12 +115,14 @@ int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
     if ((rc = ldpc_nms_decode(ctx, p->d_llr, p->B, p->T, p->alpha, p->w_in, p->w_out, p->d_soft, nullptr, p->d_hard,
                               p->d_fail, p->nms_kernel, stream))) return rc;
     if (ev) LDPC_HIP(hipEventRecord(ev[1], s));
-    if (p->d_label_bits && p->d_nms_counts &&
-        (rc = ldpc_eval_counts(ctx, p->d_hard, p->d_label_bits, p->d_fail, p->B, p->d_nms_counts, stream))) return rc;
+    const bool want_eval = p->d_label_bits && p->d_nms_counts;
     if (p->osd_enable) {
         if (!p->d_index || !p->d_count || !p->d_cw)
             return fail(LDPC_E_ARG, "ldpc_pipeline_run: OSD stage needs d_index, d_count, d_cw");
-        if ((rc = ldpc_compact(ctx, p->d_fail, p->B, p->d_index, p->d_count, stream))) return rc;
+        if (want_eval && p->B > 0) {   // counters and the compaction's counting pass share one kernel
+            if ((rc = eval_and_compact(ctx, p->d_hard, p->d_label_bits, p->d_fail, p->B, p->d_nms_counts, p->d_index,
+                                       p->d_count, s))) return rc;
+        } else if ((rc = ldpc_compact(ctx, p->d_fail, p->B, p->d_index, p->d_count, stream))) return rc;
         if (ev) LDPC_HIP(hipEventRecord(ev[2], s));
         if (p->d_perm && p->d_parity) {   // caller wants the front-end results: two kernels
             if ((rc = ldpc_osd_front(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, nullptr, stream))) return rc;
@@ -136,7 +138,8 @@ int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
         if (p->d_label_bits && p->d_osd_counts &&
             (rc = ldpc_osd_counts(ctx, p->d_cw, p->d_label_bits, p->d_index, p->d_count, p->d_ntep, p->B, p->d_osd_counts,
                                   stream))) return rc;
-    }
+    } else if (want_eval && (rc = ldpc_eval_counts(ctx, p->d_hard, p->d_label_bits, p->d_fail, p->B, p->d_nms_counts, stream)))
+        return rc;
     return LDPC_OK;
 }
 

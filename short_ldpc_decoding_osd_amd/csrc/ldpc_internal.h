@@ -77,5 +77,7 @@ int64_t hosd_pattern_teps(int nseg, const int32_t *bounds, const int32_t *patter
 int launch_nms(ldpc_ctx *ctx, const float *d_llr, int64_t B, int T, const float *alpha, float w_in, float w_out,
                float *d_soft, float *d_traj, uint64_t *d_hard, uint8_t *d_fail, int kernel, hipStream_t st);
 int probe_dpp(bool *ror_up);
+int eval_and_compact(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_label, const uint8_t *d_fail, int64_t B,
+                     int64_t *d_counts, int32_t *d_index, int32_t *d_count, hipStream_t st);
 
 }  // namespace ldpc

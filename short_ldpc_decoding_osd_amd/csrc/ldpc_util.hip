@@ -65,17 +65,43 @@ __device__ __forceinline__ unsigned flags8(const unsigned char *flag, long long 
     return bits;
 }
 
+// EVAL: the get_eval counters of the same frames ride along (ldpc_pipeline_run: one launch instead of
+// eval_counts_kernel + compact_count_kernel; the flags are the syndrome flags either way)
+template <bool EVAL>
 __global__ __launch_bounds__(256) void compact_count_kernel(const unsigned char *__restrict__ flag, long long B,
-                                                            int *__restrict__ blocksum)
+                                                            int *__restrict__ blocksum,
+                                                            const unsigned long long *__restrict__ hard,
+                                                            const unsigned long long *__restrict__ label, int words,
+                                                            unsigned long long *__restrict__ counts)
 {
     __shared__ int part[4];
+    __shared__ unsigned long long epart[4][4];
     const long long base = (long long)blockIdx.x * kChunk + threadIdx.x * 8;
-    int c = base < B ? __popc(flags8(flag, base, B)) : 0;
+    const unsigned bits = base < B ? flags8(flag, base, B) : 0;
+    int c = __popc(bits);
+    unsigned long long ferr = 0, berr = 0, und = 0, cnt = 0;
+    if constexpr (EVAL) {
+        for (int i = 0; i < 8 && base + i < B; ++i) {
+            const long long f = base + i;
+            int e = 0;
+            for (int w = 0; w < words; ++w) e += __popcll(hard[f * words + w] ^ label[f * words + w]);
+            cnt += 1; berr += e; ferr += e != 0; und += (!((bits >> i) & 1) && e != 0);
+        }
+        cnt = wave_sum(cnt); ferr = wave_sum(ferr); berr = wave_sum(berr); und = wave_sum(und);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        part[wave] = c;
+        if constexpr (EVAL) { epart[wave][0] = cnt; epart[wave][1] = ferr; epart[wave][2] = berr; epart[wave][3] = und; }
+    }
     __syncthreads();
     if (threadIdx.x == 0) blocksum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    if constexpr (EVAL) {   // counts[] = {frames, frame_err, bit_err, undetected, synd_fail}
+        if (threadIdx.x < 4) atomicAdd(&counts[threadIdx.x], epart[0][threadIdx.x] + epart[1][threadIdx.x] + epart[2][threadIdx.x] + epart[3][threadIdx.x]);
+        if (threadIdx.x == 4) atomicAdd(&counts[4], (unsigned long long)(part[0] + part[1] + part[2] + part[3]));
+    }
 }
 
 __global__ __launch_bounds__(256) void compact_scatter_kernel(const unsigned char *__restrict__ flag, long long B,
@@ -184,13 +210,42 @@ int ldpc_compact(ldpc_ctx *ctx, const uint8_t *d_flag, int64_t B, int32_t *d_ind
     if (blocks > ctx->blocksum_cap)
         return fail(LDPC_E_UNSUPPORTED, "ldpc_compact: B=%lld exceeds the context's scratch (%lld frames)", (long long)B,
                     (long long)ctx->blocksum_cap * kChunk);
-    hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_flag, (long long)B,
-                       ctx->d_blocksum);
+    hipLaunchKernelGGL(compact_count_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, d_flag, (long long)B,
+                       ctx->d_blocksum, (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, 0,
+                       (unsigned long long *)nullptr);
     hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_flag, (long long)B,
                        ctx->d_blocksum, d_index, d_count);
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;
 }
+
+}  // extern "C"
+
+namespace ldpc {
+
+// ldpc_eval_counts + ldpc_compact on the same flags with one launch fewer (ldpc_pipeline_run)
+int eval_and_compact(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_label, const uint8_t *d_fail, int64_t B,
+                     int64_t *d_counts, int32_t *d_index, int32_t *d_count, hipStream_t st)
+{
+    if (!ctx || !d_hard || !d_label || !d_fail || !d_counts || !d_index || !d_count || B <= 0 || B > 0x7FFFFFFFLL)
+        return fail(LDPC_E_ARG, "eval_and_compact: bad arguments");
+    const int64_t blocks = (B + kChunk - 1) / kChunk;
+    if (blocks > ctx->blocksum_cap)
+        return fail(LDPC_E_UNSUPPORTED, "ldpc_compact: B=%lld exceeds the context's scratch (%lld frames)", (long long)B,
+                    (long long)ctx->blocksum_cap * kChunk);
+    hipLaunchKernelGGL(compact_count_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, d_fail, (long long)B,
+                       ctx->d_blocksum, reinterpret_cast<const unsigned long long *>(d_hard),
+                       reinterpret_cast<const unsigned long long *>(d_label), (ctx->code.n + 63) / 64,
+                       reinterpret_cast<unsigned long long *>(d_counts));
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_fail, (long long)B,
+                       ctx->d_blocksum, d_index, d_count);
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+}  // namespace ldpc
+
+extern "C" {
 
 int ldpc_pack_bits(ldpc_ctx *ctx, const void *d_bits, int32_t elem_size, int64_t B, uint64_t *d_words, void *stream)
 {
