@@ -4,23 +4,28 @@
 //   swapped_info / identify_mrb / full_gf2elim   PB_OSD/pb_testing.py:231-320 (== FS_OSD/fs_testing.py:233-322)
 //   generate_teps / convention_osd_main           FS_OSD/convention_osd.py:13-76
 //
-// One frame per wavefront, no MFMA (bit and compare work).  Two kernels:
+// One frame per wavefront, no MFMA (bit and compare work); the long kernels run one wavefront per
+// workgroup (compile-time LDS addresses, frames balanced by the hardware dispatcher).  Kernels:
 //
-//   osd_front_kernel   reliability sort (rank sort of |y|, ties -> lower index), gather of the
-//                      G columns in sorted order, GF(2) Gauss-Jordan with the reference's pivot
-//                      rule, MRB/LRB bookkeeping.  The matrix lives COLUMN-major in registers:
-//                      lane p holds columns p and p+64 as two 64-bit words (bit = row), so the
-//                      column gather is one load per lane, a pivot step is a handful of
-//                      wave-uniform scalars (v_readlane / ballot / s_ff1) plus ~10 VALU ops, row
-//                      exchanges only touch a lane-resident row map and column exchanges move
-//                      two lanes.  Output: perm (original bit at each primed position) and the
-//                      rows of P' (G' = [I | P']) after a 64x64 bit transpose through lane
-//                      shuffles.
-//   osd_search_kernel  conventional order-p search over the reference's TEP table: per frame a
-//                      byte-indexed LUT of partial |y'| sums in LDS (8 x 256 floats), each lane
-//                      evaluates one TEP per round: parity word = d0 ^ P'[i] ^ P'[j] ..., metric
-//                      = flipped-MRB weights + 8 LUT terms in a FIXED order (the canonical order
-//                      the oracle uses, see oracle/np_oracle.py weighted_distance), first minimum.
+//   osd_front_kernel    reliability sort (rank sort of |y|, ties -> lower index), gather of the
+//                       G columns in sorted order, GF(2) Gauss-Jordan with the reference's pivot
+//                       rule (ge_columns, ldpc_wave.h), MRB/LRB bookkeeping.  The matrix lives
+//                       COLUMN-major in registers: lane p holds columns p and p+64 as two 64-bit
+//                       words (bit = row), so the column gather is one load per lane, a pivot step
+//                       is a handful of wave-uniform scalars (v_readlane / compare / s_ff1) plus
+//                       ~12 VALU ops, row exchanges only touch a lane-resident row map and column
+//                       exchanges move two lanes.  Output: perm (original bit at each primed
+//                       position) and the rows of P' (G' = [I | P']) after a 64x64 bit transpose.
+//   osd_search2_kernel  conventional order 2, register-resident, two-stage scan with an exact
+//                       prefix early exit and survivor compaction (the headline configuration).
+//   osd_search_kernel   conventional order-p search over the reference's TEP table: per frame a
+//                       byte-indexed LUT of partial |y'| sums in LDS (8 x 256 floats), each lane
+//                       evaluates one TEP per round: parity word = d0 ^ P'[i] ^ P'[j] ..., metric
+//                       = flipped-MRB weights + 8 LUT terms in a FIXED order (the canonical order
+//                       the oracle uses, see oracle/np_oracle.py weighted_distance), first minimum.
+//   osd_fs_kernel       FS-OSD (FS_OSD/fs_testing.py:22-64,129-161), 64 TEPs per round.
+//   osd_pb_kernel       PB-OSD (PB_OSD/pb_testing.py:35-41,100-149,366-500), best-first frontier.
+//   osd_ge_kernel       full_gf2elim on caller-supplied matrices; osd_counts_kernel: success counters.
 #include <math.h>
 #include <stdlib.h>
 
