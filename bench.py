@@ -130,8 +130,8 @@ def cpu_baseline(code_G, code_H, order, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=os.environ.get("LDPC_BENCH_WORKLOAD", "nms10_osd2"), choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
