@@ -4,7 +4,7 @@ set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; B=$R/bench.py; O=$R/gpurun_out; TAG=${1:-p}
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python3 $B --steps 20 --warmup 3 --no-cpu-baseline --no-overlap-pass > $O/${TAG}_stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python3 $B --no-cpu-baseline --no-overlap-pass > $O/${TAG}_stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${TAG}_$c -- python3 $B --steps 10 --warmup 2 --no-cpu-baseline --no-overlap-pass > $O/${TAG}_$c.log 2>&1
 done
