@@ -2,24 +2,31 @@
 """Headline benchmark: decoded frames/s (+FER) for the (128,64) CCSDS LDPC code,
 NMS-10 (+ OSD-p on the syndrome-failed frames) at Eb/N0 = 2.5 dB on synthetic AWGN frames.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload nms10_osd2|nms10_osd0|nms10]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload nms10_osd2|nms10_osd0|nms10|nms10_fs2|nms10_pb3]
 
 One "step" = one pass of the hot path over one device-resident batch of frames:
-NMS-10 -> failed-frame compaction -> OSD-p on the failures -> error counters, all on the GPU
-with no host round trip, enqueued by ONE call into the C ABI (ldpc_pipeline_run).  Inputs are generated on the device before the timed region.
-For N > 1 the driver launches one rank per GPU (torch.distributed, backend nccl = RCCL);
-frames shard across ranks (weak scaling: fixed per-GPU batch) and the only collective is ONE
-all-reduce of the error counters per measurement, inside the timed region.
+NMS-10 -> error counters + failed-frame compaction -> OSD-p on the failures -> OSD counters, all on the GPU
+with no host round trip, enqueued by ONE call into the C ABI (ldpc_pipeline_run).  The timed loop ROTATES over
+--batches (default 4) distinct pre-generated batches, each with its own buffers, so that inputs + outputs of one
+rotation (4 x 136 MB) exceed the 256 MiB Infinity Cache and every step streams from / to HBM.
 
-Prints ONE JSON line (rank 0) with the contract fields plus "roofline" (dominant kernel,
-HIP-event timed) and "cpu_baseline" (the C oracle = scalar port of the same math, timed on
-this host on a bounded sample; N = 1 only).
+Ranks: one process per GPU (torch.distributed, backend nccl = RCCL).  Under a launcher (torchrun: WORLD_SIZE set)
+this process is one rank.  Started plainly with --gpus N > 1, it spawns the N ranks itself as child processes
+BEFORE touching any GPU, relays rank 0's JSON line and fails if any rank fails or fewer than N GPUs are visible.
+Frames shard across ranks (weak scaling: fixed per-GPU batch); the only collective is ONE all-reduce of the
+error counters per measurement, inside the timed region.
+
+Prints ONE JSON line (rank 0) with the contract fields plus "roofline" (dominant kernel, HIP-event timed),
+"cpu_baseline" (the C oracle = scalar port of the same math on this host's cores, bounded sample, N = 1 only;
+with its FER and, as `reference_equivalent`, the dense NumPy mirror of the reference's formulation on one core)
+and "fer_vs_cpu" (north_star acceptance: FER within +-5 % of the float CPU path in the same run).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,12 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 SNR_DB = 2.5
 T_ITERS = 10
-ALPHA = 0.669435  # softplus(-0.048): the reference's shipped (untrained) NMS-1 weight, ms_test.py:73
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 NMS_BYTES_PER_FRAME = 1040  # 512 B LLR in + 512 B posterior out + 16 B hard word
 OSD_BYTES_PER_FRAME = 536   # 512 B channel values in + 16 B codeword + 4 B metric + 4 B TEP id
@@ -50,9 +53,59 @@ WORKLOADS = {
 OSD_ALGO = {"nms10_fs2": 1, "nms10_pb3": 2}
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=os.environ.get("LDPC_BENCH_WORKLOAD", "nms10_osd2"), choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU and step (0 = the workload's default)")
+    ap.add_argument("--batches", type=int, default=4, help="distinct pre-generated batches the timed loop rotates over")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap-pass", dest="overlap_pass", action="store_false",
+                    help="skip the informative 3-stream pass that follows the timed region")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams of the timed region; >1 keeps several batches in flight (batch i runs on stream i mod N)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# rank launcher: the parent never touches a GPU
+# ---------------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    import socket
+
+    import torch
+    n = args.gpus
+    have = torch.cuda.device_count()     # (counts devices without initialising one)
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible -- refusing to report a {n}-GPU number")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    if any(codes) or not line:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise SystemExit(f"bench.py --gpus {n}: rank exit codes {codes}" + ("" if line else ", no JSON line from rank 0"))
+    print(line[-1], flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------
 def make_frames(dec, B, seed):
     """Synthetic test frames on the device (Testing_data_gen_128/data_generating.py:13-51):
     random message . G, BPSK 0 -> +1, y = (1 - 2c)(1 + sigma N(0,1)), unscaled float32."""
+    import numpy as np
+    import torch
     g = torch.Generator(device=dec.device).manual_seed(seed)
     G = torch.from_numpy(dec.code.G).to(device=dec.device, dtype=torch.float32)
     sigma = float(np.sqrt(1.0 / (2.0 * (dec.k / dec.n) * 10.0 ** (SNR_DB / 10.0))))
@@ -69,10 +122,10 @@ def make_frames(dec, B, seed):
     return y, labels
 
 
-def pmc_traffic(kernel, workload, B):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes) -- only when the
-    profile was taken on this very workload; otherwise null."""
+def pmc_profile(kernel, workload, B):
+    """(HBM bytes per launch, VALU issue fraction) of `kernel` from the committed rocprofv3 PMC passes
+    (scripts/profile_bench.sh + scripts/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE
+    doubled as the gfx950 guide prescribes) -- only when the profile was taken on this very workload; else nulls."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_counters_*.json")), reverse=True):
         try:
@@ -81,16 +134,22 @@ def pmc_traffic(kernel, workload, B):
             continue
         if prof.get("bench_workload") != workload or prof.get("frames_per_launch") != B:
             continue
-        for name, counters in prof.get("per_launch_mean", {}).items():
-            if kernel in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-                return (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
-    return None
+        for name, c in prof.get("per_launch_mean", {}).items():
+            if kernel in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                issue = c.get("valu_issue_frac")
+                if issue is None and c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c:
+                    issue = c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0)
+                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, issue, os.path.relpath(path, ROOT)
+    return None, None, None
 
 
-def cpu_baseline(code_G, code_H, order, seconds_target=12.0):
+def cpu_baseline(code_G, code_H, order, alpha, seconds_target=12.0):
     """The C oracle (scalar port of the same math) on this host: frames are split over the host cores this
-    process may use (the C calls release the GIL), bounded sample; the one-thread rate is reported alongside."""
+    process may use (the C calls release the GIL), bounded sample; the one-thread rate and the sample's FER are
+    reported alongside, plus the dense NumPy mirror of the reference's own formulation on one core."""
     import concurrent.futures
+
+    import numpy as np
 
     from oracle import c_oracle, np_oracle
     rng = np.random.default_rng(20241020)
@@ -101,12 +160,17 @@ def cpu_baseline(code_G, code_H, order, seconds_target=12.0):
     cores = max(1, min(cores, 16))   # a one-GPU box shares its host: 16 cores per GPU
 
     def once(yb, cb):
-        soft = c_oracle.nms(code_H, yb, T_ITERS, ALPHA)
-        _, fail, _ = c_oracle.evaluate(code_H, soft, cb)
+        soft = c_oracle.nms(code_H, yb, T_ITERS, alpha)
+        _, fail, cnt = c_oracle.evaluate(code_H, soft, cb)
+        wrong = 0
+        nfail = int(cnt["synd_fail"])
         if order is not None:
             idx = np.flatnonzero(fail)
             if idx.size:
-                c_oracle.conv_osd(code_G, yb[idx], cb[idx], order)
+                wrong = int((~c_oracle.conv_osd(code_G, yb[idx], cb[idx], order)["correct"]).sum())
+        else:
+            wrong = nfail
+        return np.array([yb.shape[0], cnt["frame_err"], cnt["undetected"], nfail, wrong], dtype=np.int64)
 
     frames = 2000
     y, cw = np_oracle.make_frames(code_G, SNR_DB, frames, rng)
@@ -118,35 +182,49 @@ def cpu_baseline(code_G, code_H, order, seconds_target=12.0):
     parts = [(y[i * per:(i + 1) * per], cw[i * per:(i + 1) * per]) for i in range(cores)]
     with concurrent.futures.ThreadPoolExecutor(max_workers=cores) as ex:
         t0 = time.perf_counter()
-        list(ex.map(lambda p: once(*p), parts))
+        c = sum(ex.map(lambda p: once(*p), parts))
         dt = time.perf_counter() - t0
+    # "reference-equivalent CPU" (SURVEY 8(d)(i)): the reference's dense [B,64,128] formulation (ms_test.py:124-228) and
+    # its per-frame int-matmul OSD (convention_osd.py:49-76), restated in NumPy, one core
+    nref = 400
+    yr, cr = y[:nref], cw[:nref]
+    t0 = time.perf_counter()
+    soft = np_oracle.nms_dense(yr, code_H, T_ITERS, alpha)[-1]
+    t_nms = time.perf_counter() - t0
+    _, _, _, failed = np_oracle.evaluate(soft, cr, code_H)
+    t0 = time.perf_counter()
+    nosd = 0
+    if order is not None:
+        teps = np_oracle.tep_matrix(64, order)
+        for i in list(failed)[:40]:
+            yp, lp, Gp, _, _ = np_oracle.swapped_info(yr[i], cr[i], code_G)
+            np_oracle.convention_osd(yp, lp, Gp, order, teps)
+            nosd += 1
+    t_osd = (time.perf_counter() - t0) / max(nosd, 1) * len(failed)      # scaled to all failures of the sample
+    ref_rate = nref / (t_nms + (t_osd if order is not None else 0.0))
+    e2e = int(c[4] + c[2]) if order is not None else int(c[1])
     return dict(value=per * cores / dt, unit="frames/s", cores=cores, kind="port",
                 sample=f"{per * cores} frames at {SNR_DB} dB through oracle/ldpc_oracle.c (gcc -O2, scalar code, {cores} "
                        f"threads of {per} frames): NMS-{T_ITERS}"
                        + (f" + OSD-{order} on the syndrome failures" if order is not None else "")
-                       + f", {dt:.1f} s; one thread alone: {rate1:.0f} frames/s")
+                       + f", {dt:.1f} s; one thread alone: {rate1:.0f} frames/s",
+                frames=int(c[0]), fer_nms=float(c[1] / c[0]), syndrome_fail_rate=float(c[3] / c[0]),
+                fer_end_to_end=float(e2e / c[0]), frame_errors_end_to_end=e2e,
+                reference_equivalent=dict(value=ref_rate, unit="frames/s", cores=1, kind="port",
+                                          sample=f"dense NumPy mirror of ms_test.py:124-228 on {nref} frames ({nref / t_nms:.0f} frames/s)"
+                                                 + (f" + NumPy convention_osd_main order {order} timed on {nosd} of the {len(failed)} "
+                                                    f"failures ({t_osd / max(len(failed), 1) * 1e3:.0f} ms per failed frame)" if order is not None else "")))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=os.environ.get("LDPC_BENCH_WORKLOAD", "nms10_osd2"), choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (0 = the workload's default)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap-pass", dest="overlap_pass", action="store_false",
-                    help="skip the informative 3-stream pass that follows the timed region")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams; >1 pipelines independent batches so the VALU-bound NMS of one batch overlaps the "
-                         "OSD scan of another (each stream owns a batch and a full set of buffers)")
-    args = ap.parse_args()
+def run_rank(args):
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("LDPC_BENCH_FORCE_DIST"):   # (the variable rehearses the RCCL path with one rank)
@@ -154,32 +232,33 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from short_ldpc_decoding_osd_amd import Code
-    from short_ldpc_decoding_osd_amd.sharding import allreduce_counters
-    from short_ldpc_decoding_osd_amd.runtime import Decoder
-
-    order, default_batch, cfg_name = WORKLOADS[args.workload]
-    B = args.batch or default_batch
-    dec = Decoder(Code(), local_rank)
-    y, labels = make_frames(dec, B, seed=20241020 + rank)
     from short_ldpc_decoding_osd_amd._lib import TIMING_SLOTS
     from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline
+    from short_ldpc_decoding_osd_amd.runtime import Decoder
+    from short_ldpc_decoding_osd_amd.sharding import allreduce_counters
+    from short_ldpc_decoding_osd_amd.weights import STORED_NMS1_WEIGHT, softplus32
+
+    alpha = float(softplus32(STORED_NMS1_WEIGHT))      # the reference's shipped (untrained) NMS-1 weight, ms_test.py:73
+    order, default_batch, cfg_name = WORKLOADS[args.workload]
+    B = args.batch or default_batch
+    nb = max(1, args.batches, args.streams)
+    dec = Decoder(Code(), local_rank)
     algo = OSD_ALGO.get(args.workload, 0)
-    step = BatchPipeline(dec, B, T_ITERS, ALPHA, osd_order=order, osd_algo=algo, snr_db=SNR_DB).bind(y, labels)
-    lanes = [(torch.cuda.current_stream(), step)]
-    for extra in range(1, max(1, args.streams)):      # every extra stream decodes its own batch
-        y2, lab2 = make_frames(dec, B, seed=20241020 + rank + 1000 * extra)
-        lanes.append((torch.cuda.Stream(), BatchPipeline(dec, B, T_ITERS, ALPHA, osd_order=order, osd_algo=algo, snr_db=SNR_DB).bind(y2, lab2)))
+    pipes = []
+    for i in range(nb):                                # distinct batches, each with its own buffers
+        y, labels = make_frames(dec, B, seed=20241020 + rank + 1000 * i)
+        pipes.append(BatchPipeline(dec, B, T_ITERS, alpha, osd_order=order, osd_algo=algo, snr_db=SNR_DB).bind(y, labels))
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(1, max(1, args.streams))]
 
     def run_step(k, slot=-1):
-        st, pipe = lanes[k % len(lanes)]
-        with torch.cuda.stream(st):
-            pipe.run(timing_slot=slot)
+        with torch.cuda.stream(streams[(k % nb) % len(streams)]):
+            pipes[k % nb].run(timing_slot=slot)
 
-    for k in range(max(args.warmup, len(lanes))):
+    for k in range(max(args.warmup, nb)):
         run_step(k)
     torch.cuda.synchronize()
-    for _, pipe in lanes:
-        pipe.reset_counters()
+    for p in pipes:
+        p.reset_counters()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -187,11 +266,11 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         run_step(k, slot=k % TIMING_SLOTS)             # library-side HIP events around the hot kernels
-    for st, _ in lanes[1:]:
+    for st in streams[1:]:
         torch.cuda.current_stream().wait_stream(st)
-    total = lanes[0][1].counters()
-    for _, pipe in lanes[1:]:
-        total += pipe.counters()
+    total = pipes[0].counters().clone()
+    for p in pipes[1:]:
+        total += p.counters()
     counters = allreduce_counters(total)               # the path's one exchange step (RCCL over xGMI)
     torch.cuda.synchronize()
     if dist is not None:
@@ -202,28 +281,31 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dec.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
     c = counters.cpu().numpy().astype(np.int64)
 
-    # informative second pass (not the headline): the same steps with three batches in flight on three
-    # streams, where the NMS of one batch overlaps the OSD kernels (and the kernel tails) of another
+    # error counts over the DISTINCT frames only (batch i was decoded steps_i times with identical results)
+    distinct = torch.zeros(8, dtype=torch.int64, device=dec.device)
+    for i, p in enumerate(pipes):
+        runs = len(range(i, args.steps, nb))
+        if runs:
+            distinct += p.counters() // runs
+    d = allreduce_counters(distinct).cpu().numpy().astype(np.int64)
+
+    # informative second pass (not the headline): the same steps with three batches in flight on three streams,
+    # where the NMS of one batch overlaps the OSD kernels (and the kernel tails) of another
     overlap = None
-    if args.streams == 1 and args.overlap_pass and order is not None:
-        olanes = list(lanes)
-        for extra in (1, 2):
-            y2, lab2 = make_frames(dec, B, seed=20241020 + rank + 1000 * extra)
-            olanes.append((torch.cuda.Stream(), BatchPipeline(dec, B, T_ITERS, ALPHA, osd_order=order, osd_algo=algo,
-                                                              snr_db=SNR_DB).bind(y2, lab2)))
+    if args.streams == 1 and args.overlap_pass and order is not None and nb >= 3:
+        ost = [torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()]
         for k in range(6):
-            with torch.cuda.stream(olanes[k % 3][0]):
-                olanes[k % 3][1].run()
+            with torch.cuda.stream(ost[k % 3]):
+                pipes[k % 3].run()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         t1 = time.perf_counter()
         for k in range(args.steps):
-            with torch.cuda.stream(olanes[k % 3][0]):
-                olanes[k % 3][1].run()
+            with torch.cuda.stream(ost[k % 3]):
+                pipes[k % 3].run()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -233,60 +315,90 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e2 = float(t.item())
         overlap = {"streams": 3, "value": B * args.steps * world / e2, "unit": "frames/s", "ms_per_step": 1e3 * e2 / args.steps,
-                   "note": "same step, three independent batches in flight (bench.py --streams 3 makes this the timed region)"}
+                   "note": "same step, three independent batches in flight on three streams of one context "
+                           "(bench.py --streams 3 makes this the timed region)"}
 
     frames_total = int(c[0])
     assert frames_total == B * args.steps * world, (frames_total, B, args.steps, world)
     value = frames_total / elapsed
-    fer_nms = c[4] / max(c[0], 1)  # syndrome failures / frames (what is forwarded to the OSD)
     res = {
         "metric": "decoded frames/sec + FER, (128,64) LDPC NMS-10+OSD-2 @ 2.5 dB",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload} -- {cfg_name}", "code": "CCSDS (128,64)", "snr_db": SNR_DB,
-                   "nms_iterations": T_ITERS, "alpha": ALPHA, "osd_order": order, "frames_per_gpu": B,
+                   "nms_iterations": T_ITERS, "alpha": alpha, "osd_order": order, "frames_per_gpu": B,
                    "global_frames_per_step": B * world, "parallelism": f"frame-sharded x{world}",
-                   "nms_kernel": {1: "generic", 2: "qc16"}[dec.nms_kernel], "streams": len(lanes)},
-        "fer": {"nms_frame_error_rate": c[1] / max(c[0], 1), "nms_syndrome_fail_rate": fer_nms,
-                "nms_undetected": int(c[3]), "nms_ber": c[2] / max(c[0] * dec.n, 1)},
+                   "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+                   "distinct_batches_per_gpu": nb, "distinct_frames": int(d[0]),
+                   "bytes_in_plus_out_per_rotation": int(nb * B * (NMS_BYTES_PER_FRAME + 1)),
+                   "nms_kernel": {1: "generic", 2: "qc16"}[dec.nms_kernel], "streams": len(streams)},
+        "fer": {"frames": int(d[0]), "nms_frame_error_rate": d[1] / max(d[0], 1), "nms_syndrome_fail_rate": d[4] / max(d[0], 1),
+                "nms_undetected": int(d[3]), "nms_ber": d[2] / max(d[0] * dec.n, 1)},
     }
+    e2e_errors = int(d[1])
     if order is not None:
-        osd_frames, osd_wrong, teps = int(c[5]), int(c[6]), int(c[7])
+        osd_frames, osd_wrong, teps = int(d[5]), int(d[6]), int(d[7])
+        e2e_errors = osd_wrong + int(d[3])
         res["fer"].update({"osd_frames": osd_frames, "osd_fail_rate_given_nms_fail": osd_wrong / max(osd_frames, 1),
-                           "end_to_end_fer": (osd_wrong + int(c[3])) / max(c[0], 1),
+                           "end_to_end_fer": e2e_errors / max(d[0], 1), "frame_errors_end_to_end": e2e_errors,
                            "mean_teps": teps / max(osd_frames, 1)})
-
     if overlap is not None:
         res["overlap"] = overlap
+    fer_ok = True
     if rank == 0:
         # roofline of the dominant kernel from the HIP events recorded on the launch stream
-        tm = np.array([step.timing(k) for k in range(min(args.steps, TIMING_SLOTS))])
+        tm = np.array([pipes[0].timing(k) for k in range(min(args.steps, TIMING_SLOTS))])
         nms_name = {1: "nms_generic_kernel", 2: "nms_qc16_kernel"}[dec.nms_kernel]
         kern = {nms_name: (float(tm[:, 0].mean()), NMS_BYTES_PER_FRAME * B)}
         if order is not None:
             f_per_step = c[5] / (args.steps * world)
             if tm[:, 1].mean() > 0.02:   # two-kernel OSD (front end + search through the workspace)
                 kern["osd_front_kernel"] = (float(tm[:, 1].mean()), (512 + 640) * f_per_step)
-                sname = {1: "osd_fs_kernel", 2: "osd_pb_kernel"}.get(algo, "osd_search2_kernel" if order == 2 else "osd_search_kernel")
+                sname = {1: "osd_fs_kernel", 2: "pb_osd (three kernels)"}.get(algo, "osd_search2_kernel" if order == 2 else "osd_search_kernel")
                 kern[sname] = (float(tm[:, 2].mean()), (1152 + 24) * f_per_step)
             else:                        # OSD through the context workspace: one combined duration
                 kern["osd_front+search"] = (float(tm[:, 2].mean()), OSD_BYTES_PER_FRAME * f_per_step)
         name = max(kern, key=lambda k: kern[k][0])
         ms, nbytes = kern[name]
         achieved = nbytes / (ms * 1e-3) / 1e9
+        traffic, issue, prof_path = pmc_profile(name, args.workload, B)
         res["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(name, args.workload, B), "avg_launch_ms": ms,
-                           "algorithmic_bytes_per_launch": float(nbytes),
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "issue_frac": issue, "pmc_profile": prof_path,
+                           "avg_launch_ms": ms, "algorithmic_bytes_per_launch": float(nbytes),
                            "all_kernels_ms": {k: v[0] for k, v in kern.items()},
                            "all_kernels_GBps": {k: v[1] / (v[0] * 1e-3) / 1e9 for k, v in kern.items()},
-                           "note": "no contraction on this path (no MFMA); NMS and the OSD front end are instruction-issue bound "
-                                   "(VALU 100 % / 90 % busy), the order-2 scan latency bound at 2.7 waves/SIMD -- see DESIGN.md 5; HBM fraction reported as mandated"}
+                           "note": "no contraction on this path (no MFMA); the kernels are instruction-issue bound: issue_frac = "
+                                   "vector-issue cycles / cycles the 1024 SIMDs had during the launch (committed PMC pass, "
+                                   "SQ_ACTIVE_INST_VALU); HBM fraction reported as mandated -- see DESIGN.md 5"}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(dec.code.G, dec.code.H, order)
+            cpu = cpu_baseline(dec.code.G, dec.code.H, order, alpha)
+            res["cpu_baseline"] = cpu
+            # north_star acceptance: FER within +-5 % (relative) of the float CPU path of the same run, judged when both
+            # sides hold >= 1600 frame errors; sigma of the ratio of two Poisson counts
+            eg, ec = e2e_errors, cpu["frame_errors_end_to_end"]
+            fg, fc = eg / max(d[0], 1), cpu["fer_end_to_end"]
+            rel = fg / fc - 1.0 if fc > 0 else float("nan")
+            two_sigma = 2.0 * float(np.sqrt(1.0 / max(eg, 1) + 1.0 / max(ec, 1)))
+            enough = eg >= 1600 and ec >= 1600
+            fer_ok = (abs(rel) <= 0.05) if enough else True
+            res["fer_vs_cpu"] = {"gpu_fer_end_to_end": fg, "cpu_fer_end_to_end": fc, "fer_rel_diff_vs_cpu": rel,
+                                 "two_sigma_of_rel_diff": two_sigma, "gpu_frame_errors": eg, "cpu_frame_errors": ec,
+                                 "judged": enough, "within_5_percent": bool(fer_ok) if enough else None}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if not fer_ok:
+        raise SystemExit("bench.py: GPU FER differs from the CPU float path by more than 5 % with >= 1600 errors on both sides")
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args, argv)
+    else:
+        run_rank(args)
 
 
 if __name__ == "__main__":

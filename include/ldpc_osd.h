@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDPC_OSD_ABI_VERSION 1
+#define LDPC_OSD_ABI_VERSION 2
 
 enum {
     LDPC_OK = 0,
@@ -97,8 +97,14 @@ uint32_t ldpc_crc32c(const void *data, uint64_t len);
 
 /* ---------------------------------------------------------------------------------------
  * Device context: uploads the packed H/G, Tanner-graph tables and TEP tables of one code
- * to one GPU.  Immutable after creation; one ctx per device; decode calls on distinct
- * streams may run concurrently.
+ * to one GPU; one ctx per device.  The constants (and the event pool of ldpc_pipeline_run's
+ * timing slots) are created here and never change afterwards.  The only state that decode calls
+ * touch is scratch memory, and that is kept PER STREAM: a mutex-guarded map stream -> workspace
+ * (front-end results of ldpc_osd_decode, PB-OSD frame lists and frontier areas), created on a
+ * stream's first call and grown on demand.  Hence decode calls issued on DIFFERENT streams of one
+ * context -- from one host thread or several -- may run concurrently, for every algorithm;
+ * calls on the SAME stream are ordered by the stream.  ldpc_compact needs no scratch at all.
+ * (ldpc_pipeline_timing slots are shared: concurrent pipelines must use different slots.)
  * ------------------------------------------------------------------------------------- */
 int ldpc_ctx_create(const ldpc_code *code, int32_t device, ldpc_ctx **out);
 void ldpc_ctx_destroy(ldpc_ctx *ctx);
@@ -149,10 +155,13 @@ int ldpc_unpack_bits(ldpc_ctx *ctx, const uint64_t *d_words, int64_t B, void *d_
  * compaction can feed the OSD without a host round trip); F is then the capacity.
  * ------------------------------------------------------------------------------------- */
 
-/* Pre-size the context's OSD workspace (1.5 KiB per frame: permutation + reduced parity rows)
- * for up to max_frames frames per ldpc_osd_decode call.  Decode calls grow it on demand, which
- * allocates -- reserve first when the calls are to be captured into a hipGraph.             */
+/* Pre-size OSD workspaces (640 B per frame: permutation + reduced parity rows) for up to max_frames
+ * frames per ldpc_osd_decode call: the NULL stream's workspace immediately, every other stream's when it
+ * is created.  Decode calls grow their stream's workspace on demand, which allocates -- so before
+ * capturing calls on a stream into a hipGraph, size that stream's workspace with
+ * ldpc_osd_reserve_stream (or run one eager call on it; PB-OSD needs the eager call).          */
 int ldpc_osd_reserve(ldpc_ctx *ctx, int64_t max_frames);
+int ldpc_osd_reserve_stream(ldpc_ctx *ctx, int64_t max_frames, void *stream);
 
 /* Per-frame GF(2) elimination on the device: full_gf2elim, PB_OSD/pb_testing.py:231-266.
  * d_rows_in/out: [F][64][2] u64 (row r of frame f, columns 0..127); d_swaps: [F][64][2] u8
@@ -176,7 +185,9 @@ typedef struct ldpc_osd_params {
     float fs_tau_e;      /* FS-OSD floor(d_min-1)/2 as the reference evaluates it (6.5)    */
     float fs_tau_psc;    /* FS-OSD tau_psc, FS_OSD/globalmap.py:50 (30)                    */
     int32_t fs_reference_quirk; /* 1: keep optimal_codeword un-updated on a tau_e hit (fs_testing.py:145) */
-    int32_t reserved;    /* 0; 1 = force the table-driven scan for order 2 (cross-check of the register-resident kernel) */
+    int32_t reserved;    /* 0; cross-check switches: bit 0 = conventional order 2 through the table-driven scan instead of
+                            the register-resident kernel; PB-OSD: bit 1 = every frame through the workgroup
+                            (sorted-chunk) kernel, bit 2 = every frame through the literal list replay       */
     void *d_aux;         /* optional DEVICE [F][4] i32, PB-OSD statistics per frame: {frontier comparisons
                             (memory_sum, pb_testing.py:122), suc counter 1 (:138), suc counter 2 (:144),
                             stop reason 0 = none / 1 = promising rule (:129) / 2 = success rule (:145)} */
@@ -190,10 +201,8 @@ typedef struct ldpc_osd_params {
  *   d_ntep    [F] i32     number of TEPs evaluated (FS: num_teps, fs_testing.py:141; PB: cost_tep_num
  *                         or N_max when no rule fired, pb_testing.py:152-155)
  * Any of d_metric/d_best/d_ntep may be NULL.
- * Concurrency: conventional and FS calls on different streams may overlap (with caller-supplied
- * d_perm/d_parity through ldpc_osd_search / ldpc_pipeline_run; ldpc_osd_decode itself uses the context's
- * one workspace).  PB-OSD calls share the context's frontier spill area and frame counter: do not
- * overlap two of them on one context -- create one context per stream.                       */
+ * Concurrency: calls on different streams may overlap, whatever the algorithm (scratch is per stream,
+ * see ldpc_ctx_create).                                                                       */
 int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
                     const ldpc_osd_params *params, uint64_t *d_cw, float *d_metric, int32_t *d_best,
                     int32_t *d_ntep, void *stream);

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Golden-vector generator -- TEST INFRASTRUCTURE, runs only in the build container.
 
-Imports the ONE hot-path module of the reference that is importable without TensorFlow,
-``LDPC_128/Ldpc_128_testing/fill_matrix_info.py`` (NumPy only), from /root/reference and
-records its outputs as small fixtures under tests/golden/:
+Imports the hot-path modules of the reference that are importable without TensorFlow --
+``LDPC_128/Ldpc_128_testing/fill_matrix_info.py`` and ``LDPC_128/Testing_data_gen_128/data_generating.py``
+(with that directory's own ``globalmap.py``), both NumPy only -- from /root/reference and records their
+outputs as small fixtures under tests/golden/:
 
   code_<name>.npz       H, G, k for each code            (Code.load_code :70-129,
                                                            Code.generator_matrix :44-69)
@@ -15,10 +16,14 @@ records its outputs as small fixtures under tests/golden/:
                         same routine as DL_OSD_Testing_serial/ordered_statistics_decoding.py:222-257,
                         as ``osd.identify_mrb`` :43-80 applies it to the permuted parity-check matrix)
 
+  testgen_ccsds.npz     testing_data_generating(code, SNR, frames) under np.random.seed(s) for three (s, SNR):
+                        the reference's frames and labels   (Testing_data_gen_128/data_generating.py:13-51)
+
 Only DATA is written (inputs and the reference's outputs); no reference source travels.
 The reference tree is imported with bytecode writing disabled so nothing is written there.
 
     python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+    python oracle/gen_golden.py testgen    # only tests/golden/testgen_ccsds.npz
 """
 import contextlib
 import io
@@ -40,9 +45,42 @@ CODES = {
 }
 
 
+TESTGEN_DIR = "/root/reference/LDPC_128/Testing_data_gen_128"
+TESTGEN_CASES = ((20241020, 2.5, 96), (7, 1.0, 64), (123456, 3.5, 64))   # (np.random.seed, SNR dB, frames)
+
+
+def gen_testgen(code):
+    """The reference's own test-frame generator (a10) on its global, here seeded, NumPy RNG."""
+    sys.path.insert(0, TESTGEN_DIR)
+    for name in ("globalmap", "data_generating"):
+        sys.modules.pop(name, None)
+    import data_generating as refgen   # the reference's module; imports the globalmap.py next to it
+    import globalmap as refgl
+    refgl.set_map("Rayleigh_fading", False)
+    refgl.set_map("ALL_ZEROS_CODEWORD_TESTING", False)
+    out = {}
+    for i, (seed, snr, frames) in enumerate(TESTGEN_CASES):
+        np.random.seed(seed)
+        data, labels = refgen.testing_data_generating(code, snr, frames)
+        assert data.dtype == np.float64 and data.shape == (frames, 128)
+        out[f"data{i}"], out[f"labels{i}"] = data, labels.astype(np.uint8)
+    out["cases"] = np.array(TESTGEN_CASES, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "testgen_ccsds.npz"), **out)
+    sys.path.remove(TESTGEN_DIR)
+    for name in ("globalmap", "data_generating"):
+        sys.modules.pop(name, None)
+    print("testgen cases", TESTGEN_CASES)
+
+
 def main():
     sys.path.insert(0, REF)
     import fill_matrix_info as ref  # the reference's own module
+    if sys.argv[1:] == ["testgen"]:
+        with contextlib.redirect_stdout(io.StringIO()):
+            code = ref.Code(CODES["ccsds_128_64"])
+        os.makedirs(OUT, exist_ok=True)
+        gen_testgen(code)
+        return
 
     os.makedirs(OUT, exist_ok=True)
     codes = {}
@@ -109,6 +147,7 @@ def main():
         os.path.join(OUT, "gf2elim_ccsds_hform.npz"),
         y=hy, perm=hperms.astype(np.int16), reduced=np.packbits(hred, axis=2), swaps=hswaps, nswaps=hns)
     print("H-form gf2elim cases", hcases, "swaps mean %.2f max %d" % (hns.mean(), hns.max()))
+    gen_testgen(code)
 
 
 if __name__ == "__main__":

@@ -26,6 +26,7 @@ from short_ldpc_decoding_osd_amd import Code, _lib  # noqa: E402
 from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline  # noqa: E402
 from short_ldpc_decoding_osd_amd.runtime import Decoder  # noqa: E402
 from short_ldpc_decoding_osd_amd.sharding import allreduce_counters, combine_fer, rank_seed, shard_range  # noqa: E402
+from short_ldpc_decoding_osd_amd.weights import softplus32  # noqa: E402
 
 ALGOS = {"conv": _lib.OSD_CONVENTIONAL, "fs": _lib.OSD_FS, "pb": _lib.OSD_PB}
 
@@ -60,7 +61,7 @@ def main():
         from short_ldpc_decoding_osd_amd import weights
         _, v = weights.parse_values_txt(args.values)
         stored = float([x for k, x in v.items() if "check" in k][0][0])
-    alpha = float(np.log1p(np.exp(stored)))                     # softplus, ms_test.py:207-208
+    alpha = float(softplus32(stored))                           # softplus, ms_test.py:207-208
     dec = Decoder(Code(), local)
     lo, hi = shard_range(args.frames, rank, world)
     mine = hi - lo

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libldpcosd.so")
 SOURCES = ["ldpc_host.cpp", "ldpc_api.hip", "ldpc_nms.hip", "ldpc_util.hip", "ldpc_osd.hip",
-           "ldpc_hosd.hip"]
+           "ldpc_osd_pb.hip", "ldpc_hosd.hip"]
 # -ffp-contract=off: the float order of the NMS / OSD metric is part of the contract (no FMA fusion)
 # -fno-slp-vectorize: packed v_pk_add_f32 is no faster than two v_add_f32 on gfx950 and blocks the
 #                      fusion of the DPP rotations into their consumers
@@ -39,8 +39,8 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "ldpc_internal.h"), os.path.join(CSRC, "ldpc_wave.h"),
-               os.path.join(HERE, "..", "include", "ldpc_osd.h")]
+    headers = [os.path.join(CSRC, h) for h in ("ldpc_internal.h", "ldpc_wave.h", "ldpc_search.h", "ldpc_osd_state.h")]
+    headers.append(os.path.join(HERE, "..", "include", "ldpc_osd.h"))
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -43,12 +43,17 @@ int ldpc_ctx_create(const ldpc_code *code, int32_t device, ldpc_ctx **out)
         if ((rc = upload(code->chk_var, &ctx->d_chk_var))) break;
         if ((rc = upload(code->var_ptr, &ctx->d_var_ptr))) break;
         if ((rc = upload(code->var_edge, &ctx->d_var_edge))) break;
-        ctx->blocksum_cap = 1 << 20;  // compaction scratch: 2^20 blocks x 2048 frames
-        if (hipMalloc((void **)&ctx->d_blocksum, sizeof(int32_t) * ctx->blocksum_cap) != hipSuccess) {
-            rc = fail(LDPC_E_NOMEM, "ldpc_ctx_create: scratch allocation failed");
-            break;
-        }
         if ((rc = probe_dpp(&ctx->dpp_ror_up))) break;
+        // event pool of ldpc_pipeline_run's timing slots: created (and recorded once: the first record of an
+        // event sets up its signal and is slow) here, so that decode calls never change the context
+        ctx->timing = new hipEvent_t[LDPC_TIMING_SLOTS * 6]();
+        for (int i = 0; i < LDPC_TIMING_SLOTS * 6 && !rc; ++i) {
+            hipError_t he = hipEventCreate(&ctx->timing[i]);
+            if (he == hipSuccess) he = hipEventRecord(ctx->timing[i], nullptr);
+            if (he != hipSuccess) rc = hip_fail(he, "timing event pool");
+        }
+        if (rc) break;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = fail(LDPC_E_HIP, "ldpc_ctx_create: stream sync failed"); break; }
         if ((rc = osd_ctx_init(ctx))) break;
         if ((rc = hosd_ctx_init(ctx))) break;
     } while (0);
@@ -65,9 +70,8 @@ void ldpc_ctx_destroy(ldpc_ctx *ctx)
     hosd_ctx_release(ctx);
     (void)hipFree(ctx->d_chk_ptr); (void)hipFree(ctx->d_chk_var);
     (void)hipFree(ctx->d_var_ptr); (void)hipFree(ctx->d_var_edge);
-    (void)hipFree(ctx->d_blocksum);
     if (ctx->timing) {
-        for (int i = 0; i < LDPC_TIMING_SLOTS * 6; ++i) (void)hipEventDestroy(ctx->timing[i]);
+        for (int i = 0; i < LDPC_TIMING_SLOTS * 6; ++i) if (ctx->timing[i]) (void)hipEventDestroy(ctx->timing[i]);
         delete[] ctx->timing;
     }
     delete ctx;
@@ -96,16 +100,6 @@ int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
     if (!p->d_hard || !p->d_fail) return fail(LDPC_E_ARG, "ldpc_pipeline_run: d_hard and d_fail are required");
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t *ev = nullptr;
-    if (!ctx->timing) {   // event pool: created on the first pipeline call (any slot), i.e. during warm-up
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone) {
-            ctx->timing = new hipEvent_t[LDPC_TIMING_SLOTS * 6];
-            for (int i = 0; i < LDPC_TIMING_SLOTS * 6; ++i) {
-                LDPC_HIP(hipEventCreate(&ctx->timing[i]));
-                LDPC_HIP(hipEventRecord(ctx->timing[i], s));   // first record of an event is slow (signal set-up): pay it here
-            }
-        }
-    }
     if (p->timing_slot >= 0) {
         if (p->timing_slot >= LDPC_TIMING_SLOTS || !ctx->timing) return fail(LDPC_E_ARG, "ldpc_pipeline_run: timing_slot %d", p->timing_slot);
         ev = ctx->timing + p->timing_slot * 6;

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ldpc_osd.h"
@@ -55,13 +57,11 @@ struct ldpc_ctx {
     uint64_t *d_Gcols = nullptr;   // [128] column v of G as a 64-bit word (bit r = G[r][v])
     uint8_t *d_tep = nullptr;      // TEP supports, order <= 3: [43745][4] (i, j, l, weight)
     uint64_t *d_Hcols = nullptr;   // [128] column v of H as a 64-bit word (bit r = H[r][v]); n = 128, m = 64 only
-    int32_t *d_blocksum = nullptr; // compaction scratch
-    int64_t blocksum_cap = 0;
     bool dpp_ror_up = true;        // probed: row_ror:n moves data towards higher lanes
     bool osd_ok = false;
     bool hosd_ok = false;
-    void *osd_state = nullptr;     // ldpc::OsdState (TEP table sizes, front-end workspace)
-    hipEvent_t *timing = nullptr;  // [LDPC_TIMING_SLOTS][6] events of ldpc_pipeline_run, created on first use
+    void *osd_state = nullptr;     // ldpc::OsdState (TEP tables; per-stream workspaces behind its mutex)
+    hipEvent_t *timing = nullptr;  // [LDPC_TIMING_SLOTS][6] events of ldpc_pipeline_run, created with the context
 };
 
 namespace ldpc {

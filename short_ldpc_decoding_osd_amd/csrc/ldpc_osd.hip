@@ -31,6 +31,8 @@
 
 #include "ldpc_internal.h"
 #include "ldpc_wave.h"
+#include "ldpc_search.h"
+#include "ldpc_osd_state.h"
 
 namespace ldpc {
 
@@ -168,109 +170,6 @@ __global__ __launch_bounds__(64) void osd_front_kernel(const float *__restrict__
 // ---------------------------------------------------------------------------------------
 // conventional order-p search (convention_osd_main, convention_osd.py:49-76)
 // ---------------------------------------------------------------------------------------
-struct __attribute__((aligned(16))) SearchLds {
-    float lut[8][256];   // lut[b][v] = sum of |y'[64+8b+t]| over the set bits t of v, ascending t
-    u64 P[64];           // rows of P'
-    float w[128];        // |y'|
-    u64 cw[2];           // codeword being assembled in original bit order
-    unsigned char perm[128];
-};
-
-template <int B>
-__device__ __forceinline__ float lut_term(const SearchLds &L, u64 D) { return lut_byte<B>(L.lut, D); }
-
-__device__ __forceinline__ float tep_cost(const SearchLds &L, float mrb, u64 D)
-{
-    float acc = mrb;
-    acc = acc + lut_term<0>(L, D); acc = acc + lut_term<1>(L, D); acc = acc + lut_term<2>(L, D); acc = acc + lut_term<3>(L, D);
-    acc = acc + lut_term<4>(L, D); acc = acc + lut_term<5>(L, D); acc = acc + lut_term<6>(L, D); acc = acc + lut_term<7>(L, D);
-    return acc;
-}
-
-// The same sum with an exact early exit: every term is >= 0, so once the prefix (MRB weights + the two
-// most reliable parity bytes) exceeds an upper bound of the final minimum the candidate can neither win
-// nor tie, and its six remaining LUT reads are skipped (the scan is LDS-bound: random LUT reads, 63 % of
-// the LDS cycles were bank conflicts).  At 2.5 dB ~93 % of the order-2 TEPs leave after two bytes.
-// Returns false for a pruned candidate; otherwise `cost` is bit-identical to tep_cost().
-__device__ __forceinline__ bool tep_cost_bounded(const SearchLds &L, float mrb, u64 D, float bound, float &cost)
-{
-    float acc = mrb + lut_term<0>(L, D);
-    acc = acc + lut_term<1>(L, D);
-    if (acc > bound) return false;
-    acc = acc + lut_term<2>(L, D); acc = acc + lut_term<3>(L, D); acc = acc + lut_term<4>(L, D);
-    acc = acc + lut_term<5>(L, D); acc = acc + lut_term<6>(L, D); acc = acc + lut_term<7>(L, D);
-    cost = acc;
-    return true;
-}
-
-// per-frame set-up shared by every search: primed-order values into LDS, hard decisions, byte
-// LUTs, and the parity discrepancy d0 of the order-0 candidate
-struct SearchFrame {
-    u64 hm, hp, d0;   // hard decisions of the MRB / parity part (y' > 0 ? 0 : 1), order-0 discrepancy
-    int o1, o2;       // original bit index of primed positions lane and 64 + lane
-};
-
-__device__ __forceinline__ SearchFrame search_prepare_regs(SearchLds &L, const float *__restrict__ y, long long src,
-                                                           int o1, int o2, u64 Prow, int lane)
-{
-    SearchFrame S;
-    S.o1 = o1;
-    S.o2 = o2;
-    const float y1 = y[src * 128 + S.o1], y2 = y[src * 128 + S.o2];   // y'[p] = y[perm[p]]
-    L.perm[lane] = (unsigned char)S.o1;
-    L.perm[lane + 64] = (unsigned char)S.o2;
-    L.w[lane] = __builtin_fabsf(y1);
-    L.w[lane + 64] = __builtin_fabsf(y2);
-    L.P[lane] = Prow;
-    if (lane < 2) L.cw[lane] = 0;
-    S.hm = __ballot(!(y1 > 0.0f));
-    S.hp = __ballot(!(y2 > 0.0f));
-    wave_fence();
-    build_byte_luts<8>(L.lut, &L.w[64], lane);
-    // d0 = (u0 . P') ^ h_parity : XOR-reduce the rows selected by the MRB hard decisions
-    S.d0 = wave_xor64(((S.hm >> lane) & 1) ? Prow : 0ull) ^ S.hp;
-    wave_fence();
-    return S;
-}
-
-__device__ __forceinline__ SearchFrame search_prepare(SearchLds &L, const float *__restrict__ y, long long src,
-                                                      const unsigned char *__restrict__ perm_in,
-                                                      const u64 *__restrict__ parity_in, long long f, int lane)
-{
-    return search_prepare_regs(L, y, src, perm_in[f * 128 + lane], perm_in[f * 128 + 64 + lane], parity_in[f * 64 + lane], lane);
-}
-
-// candidate (E = flipped MRB positions, D = parity discrepancy) -> codeword in ORIGINAL bit order
-__device__ __forceinline__ void search_finish(SearchLds &L, const SearchFrame &S, u64 E, u64 D, long long f, int lane,
-                                              u64 *__restrict__ cw_out)
-{
-    const u64 mrb_bits = S.hm ^ E, par_bits = D ^ S.hp;
-    if ((mrb_bits >> lane) & 1) atomicOr(&L.cw[S.o1 >> 6], 1ull << (S.o1 & 63));
-    if ((par_bits >> lane) & 1) atomicOr(&L.cw[S.o2 >> 6], 1ull << (S.o2 & 63));
-    wave_fence();
-    if (lane < 2) cw_out[f * 2 + lane] = L.cw[lane];
-    wave_fence();
-}
-
-// one TEP (ascending support s.x < s.y < s.z, weight s.w) -> parity discrepancy, flip mask, MRB weight sum
-__device__ __forceinline__ void tep_apply(const SearchLds &L, uchar4 s, u64 d0, u64 &D, u64 &E, float &mrb)
-{
-    D = d0; E = 0; mrb = 0.0f;
-    if (s.w > 0) { D ^= L.P[s.x]; E |= 1ull << s.x; mrb = L.w[s.x]; }
-    if (s.w > 1) { D ^= L.P[s.y]; E |= 1ull << s.y; mrb = mrb + L.w[s.y]; }
-    if (s.w > 2) { D ^= L.P[s.z]; E |= 1ull << s.z; mrb = mrb + L.w[s.z]; }
-}
-
-// wave arg-min on (cost, index): every lane returns the winner
-__device__ __forceinline__ void wave_argmin(float &best, int &bestt, u64 &bestD, u64 &bestE, int lane)
-{
-    const int w = wave_argmin_lane(best, bestt);
-    best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), w));
-    bestt = __builtin_amdgcn_readlane(bestt, w);
-    bestD = readlane64(bestD, w);
-    bestE = readlane64(bestE, w);
-}
-
 // WAVES = 1 for the long scans (one wavefront per workgroup: compile-time LDS base for the LUT reads, frames
 // balanced by the dispatcher), 4 for orders 0 and 1, where a frame is too little work to pay for a workgroup
 template <int WAVES>
@@ -544,300 +443,6 @@ __global__ __launch_bounds__(64) void osd_fs_kernel(const float *__restrict__ y,
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// PB-OSD (pb_osd, PB_OSD/pb_testing.py:100-149): best-first TEP generation from a frontier
-// (optimal_tep_sequence :366-397) with two probabilistic stopping rules
-// (acquire_prob_promising :448-461, acquire_p_e_suc :423-436, thresholds :485-500).
-// The search is sequential per frame; a wavefront owns a frame, the lanes share the frontier
-// scan (arg-min on (reliability sum, insertion number) == "first minimum in list order") and
-// the per-position set-up, everything else is wave-uniform.  All probabilities follow the float
-// conventions of the oracle (oracle/ldpc_oracle.c orc_pb_osd): float32 with det_expf (IEEE
-// + - * / only, so host and device agree bit for bit), float64 binomial-CDF recurrences,
-// threshold comparisons in float64.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float det_expf(float x)
-{
-    if (x > 88.0f) x = 88.0f;
-    if (x < -87.0f) return 0.0f;
-    const float kf = __builtin_floorf(x * 1.44269504f + 0.5f);
-    const float r = (x - kf * 0.693359375f) - kf * -2.12194440e-4f;
-    float p = 1.9875691500e-4f;
-    p = p * r + 1.3981999507e-3f;
-    p = p * r + 8.3334519073e-3f;
-    p = p * r + 4.1665795894e-2f;
-    p = p * r + 1.6666665459e-1f;
-    p = p * r + 5.0000001201e-1f;
-    const float e = (p * (r * r) + r) + 1.0f;
-    return e * __int_as_float(((int)kf + 127) << 23);
-}
-
-// Frontier = the reference's growing TEP list (optimal_tep_sequence :366-397) kept in INSERTION order:
-// a popped entry is tombstoned in place (sum = +inf), children are appended, so "first minimum in list
-// order" is the arg-min on (sum, slot).  A search that never stops visits all N_max TEPs with a list of
-// tens of thousands of entries, so the arg-min is kept hierarchical: cmin[c] = best (sum, slot) of the 64
-// slots of chunk c, smin[s] = best of the 64 chunks of super-chunk s.  A pop reads the <= 32 super-minima,
-// then re-reduces one chunk and one super-chunk: ~3 wave reductions per TEP whatever the list length.
-// Slots < kPbLdsSlots and chunk minima < kPbLdsChunks live in LDS, the rest in a per-wave global area.
-struct PbEntry {
-    float sum;          // reliability sum of the flipped MRB positions (ascending, sequential); +inf = removed
-    unsigned pos;       // slots: pos0 | pos1 << 8 | pos2 << 16 | weight << 24;  minima: slot index
-};
-constexpr int kPbLdsSlots = 512, kPbLdsChunks = 64, kPbSuper = 32;   // 32 super-chunks x 4096 slots >= 2 N_max (order 3)
-
-struct __attribute__((aligned(16))) PbLds {
-    double cdfA[65];             // P[Bin(64, p1) <= b]
-    double cdfH[65];             // P[Bin(64, 1/2) <= b] (copied once per wavefront: a global read per TEP sat on the critical path)
-    float q[128];                // sigmoid(c4 |y'_p|)
-    PbEntry fr[kPbLdsSlots];     // head of the list
-    PbEntry cmin[kPbLdsChunks];  // chunk minima of the first 4096 slots
-    PbEntry smin[kPbSuper];      // super-chunk minima
-};
-
-struct PbParams {
-    int order, nmax;
-    float c4;
-    long long cmin_off;          // offset of the spilled chunk minima inside a wave's global area
-};
-
-struct PbList {
-    PbLds *B;
-    PbEntry *spill;              // slots >= kPbLdsSlots, then chunk minima >= kPbLdsChunks at cmin_off
-    long long cmin_off;
-    __device__ __forceinline__ PbEntry slot(int i) const { return i < kPbLdsSlots ? B->fr[i] : spill[i - kPbLdsSlots]; }
-    __device__ __forceinline__ void set_slot(int i, PbEntry e) const { if (i < kPbLdsSlots) B->fr[i] = e; else spill[i - kPbLdsSlots] = e; }
-    __device__ __forceinline__ PbEntry cmin(int c) const { return c < kPbLdsChunks ? B->cmin[c] : spill[cmin_off + c - kPbLdsChunks]; }
-    __device__ __forceinline__ void set_cmin(int c, PbEntry e) const { if (c < kPbLdsChunks) B->cmin[c] = e; else spill[cmin_off + c - kPbLdsChunks] = e; }
-};
-
-// wave arg-min on (sum, index): lower index wins ties; result in every lane
-__device__ __forceinline__ void argmin_si(float &s, int &idx, int lane)
-{
-    const float m = wave_min_f32(s);
-    idx = wave_min_i32(s == m ? idx : 0x7FFFFFFF);
-    s = m;
-}
-
-__global__ __launch_bounds__(256) void osd_pb_kernel(const float *__restrict__ y, const int *__restrict__ index,
-                                                     const int *__restrict__ count, long long F,
-                                                     const unsigned char *__restrict__ perm_in,
-                                                     const u64 *__restrict__ parity_in, PbParams P,
-                                                     const double *__restrict__ cdf_half /*[65]*/,
-                                                     const double *__restrict__ coef /*[64] (64-i)/(i+1)*/,
-                                                     PbEntry *__restrict__ spill_all, long long spill_stride,
-                                                     int *__restrict__ queue /* zeroed per launch */,
-                                                     u64 *__restrict__ cw_out, float *__restrict__ metric_out,
-                                                     int *__restrict__ best_out, int *__restrict__ ntep_out,
-                                                     int *__restrict__ aux_out /*[F][4] or null*/)
-{
-    __shared__ SearchLds lds[4];
-    __shared__ PbLds pbl[4];
-    const int lane = threadIdx.x & 63;
-    SearchLds &L = lds[threadIdx.x >> 6];
-    PbLds &B = pbl[threadIdx.x >> 6];
-    long long nframes = F;
-    if (count) { const long long c = *count; nframes = c < F ? c : F; }
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    PbEntry *spill = spill_all + wave * spill_stride;
-    B.cdfH[lane] = cdf_half[lane];
-    if (lane == 0) B.cdfH[64] = cdf_half[64];
-    wave_fence();
-
-    // frames are handed out through a device counter: PB-OSD run times differ by orders of magnitude between
-    // frames (a frame on which no rule fires visits all N_max TEPs), a static assignment would wait for the
-    // unluckiest wave
-    for (;;) {
-        int fq = 0;
-        if (lane == 0) fq = atomicAdd(queue, 1);
-        const long long f = __builtin_amdgcn_readfirstlane(fq);
-        if (f >= nframes) break;
-        const long long src = index ? index[f] : f;
-        const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
-        B.q[lane] = 1.0f / (1.0f + det_expf(-(P.c4 * L.w[lane])));
-        B.q[lane + 64] = 1.0f / (1.0f + det_expf(-(P.c4 * L.w[lane + 64])));
-        wave_fence();
-        // sequential (ascending position) means / product, as the oracle defines them
-        float a1 = 0.0f, aw = 0.0f, at = 0.0f, spl = 1.0f;
-#pragma unroll 4
-        for (int p = 0; p < 64; ++p) {
-            a1 = a1 + B.q[64 + p];
-            aw = aw + L.w[64 + p];
-            at = at + B.q[p];
-            spl = spl * (1.0f - B.q[p]);
-        }
-        const float p1 = a1 / 64.0f, lrb_mean = aw / 64.0f, pt = at / 64.0f;
-        // binomial CDF tables by the pmf recurrence (float64): full table for p1, up to `order` for pt
-        double niu;
-        {
-            double q = 1.0 - (double)p1, t = q;
-            for (int s = 0; s < 6; ++s) t = t * t;
-            const double ratio = (double)p1 / q;
-            double acc = t;
-            if (lane == 0) B.cdfA[0] = acc;
-#pragma unroll 2
-            for (int i = 0; i < 64; ++i) {
-                t = t * coef[i] * ratio;
-                acc = acc + t;
-                if (lane == 0) B.cdfA[i + 1] = acc;
-            }
-            q = 1.0 - (double)pt; t = q;
-            for (int s = 0; s < 6; ++s) t = t * t;
-            const double ratio2 = (double)pt / q;
-            acc = t;
-            for (int i = 0; i < P.order; ++i) { t = t * coef[i] * ratio2; acc = acc + t; }
-            niu = acc;
-        }
-        const double p_t_suc = 0.99 * niu, p_t_pro = 0.002 * __builtin_sqrt((1.0 - niu) / (double)P.nmax);
-        if (lane == 0) {   // starting point: the single TEP {k-1} (pb_testing.py:109-110)
-            PbEntry e0; e0.sum = L.w[63]; e0.pos = 63u | (1u << 24); B.fr[0] = e0;
-            PbEntry m0; m0.sum = e0.sum; m0.pos = 0; B.cmin[0] = m0; B.smin[0] = m0;
-        }
-        wave_fence();
-        int nused = 1, nlive = 1, ntep = P.nmax, bestidx = 0, stop = 0, cmp = 0, suc1 = 0, suc2 = 0;
-        int tail_ck = 0, tail_ci = 0, tail_sk = 0, tail_si = 0;   // last chunk / super-chunk of the list and their minima
-        float tail_cs = L.w[63], tail_ss = L.w[63];
-        float best = tep_cost(L, 0.0f, S.d0);
-        u64 bestD = S.d0, bestE = 0;
-        const PbList FL{&B, spill, P.cmin_off};
-        for (int j = 0; j < P.nmax - 1 && nlive > 0; ++j) {
-            // first minimum of the list = arg-min on (sum, slot), read off the super-chunk minima
-            const int nsuper = (nused + 4095) >> 12;
-            float ms = __builtin_inff();
-            int mi = 0x7FFFFFFF;
-            if (lane < nsuper) { const PbEntry t = B.smin[lane]; ms = t.sum; mi = (int)t.pos; }
-            argmin_si(ms, mi, lane);
-            cmp += nlive == 1 ? 1 : 2;
-            // Both levels of the list that this pop touches are loaded NOW, side by side: the 64 slots of the
-            // popped slot's chunk (lane mi & 63 of it is the popped entry itself) and the 64 chunk minima of its
-            // super-chunk.  Everything that changes below (the tombstone, children that land in the same chunk,
-            // the new chunk minimum) is patched into these registers, so one round trip to the spilled part of the
-            // list (global memory) is on the critical path of a TEP instead of three dependent ones.
-            const int ck0 = mi >> 6, sk0 = ck0 >> 6;
-            PbEntry mys, myc;
-            mys.sum = myc.sum = __builtin_inff(); mys.pos = 0; myc.pos = 0x7FFFFFFFu;
-            if (ck0 * 64 + lane < nused) mys = FL.slot(ck0 * 64 + lane);
-            if ((sk0 * 64 + lane) * 64 < nused) myc = FL.cmin(sk0 * 64 + lane);
-            PbEntry e;
-            e.sum = ms;
-            e.pos = (unsigned)__builtin_amdgcn_readlane((int)mys.pos, mi & 63);
-            const int ew = (int)(e.pos >> 24);
-            const int p0 = e.pos & 0xFF, pA = (e.pos >> 8) & 0xFF, pB = (e.pos >> 16) & 0xFF;
-            const int last = ew == 1 ? p0 : (ew == 2 ? pA : pB);
-            const int prev = ew == 2 ? p0 : pA;     // second largest (ew > 1)
-            // children (wave-uniform): extended e U {63}, adjacent = largest index moved down by one
-            PbEntry c1, c2;
-            c1.sum = c2.sum = __builtin_inff(); c1.pos = c2.pos = 0;
-            bool has1 = false, has2 = false;
-            if (last < 63 && ew < P.order) {
-                c1.pos = (e.pos & 0x00FFFFFFu) | (63u << (8 * ew)) | ((unsigned)(ew + 1) << 24);
-                c1.sum = e.sum + L.w[63];
-                has1 = true;
-            }
-            if (ew > 1) {
-                if (last - prev > 1) {
-                    c2.pos = (e.pos & ~(0xFFu << (8 * (ew - 1)))) | ((unsigned)(last - 1) << (8 * (ew - 1)));
-                    const int q0 = c2.pos & 0xFF, q1 = (c2.pos >> 8) & 0xFF, q2 = (c2.pos >> 16) & 0xFF;
-                    float sacc = L.w[q0] + L.w[q1];
-                    if (ew > 2) sacc = sacc + L.w[q2];
-                    c2.sum = sacc;
-                    has2 = true;
-                }
-            } else if (last - 1 > -1) {
-                c2.pos = (unsigned)(last - 1) | (1u << 24);
-                c2.sum = L.w[last - 1];
-                has2 = true;
-            }
-            if (has2 && !has1) { c1 = c2; has1 = true; has2 = false; }      // children in list order: c1 then c2
-            const int s1 = nused, s2 = nused + 1;
-            if (lane == 0) {
-                PbEntry dead;
-                dead.sum = __builtin_inff(); dead.pos = 0;
-                FL.set_slot(mi, dead);
-                if (has1) FL.set_slot(s1, c1);
-                if (has2) FL.set_slot(s2, c2);
-            }
-            nused += (has1 ? 1 : 0) + (has2 ? 1 : 0);
-            nlive += (has1 ? 1 : 0) + (has2 ? 1 : 0) - 1;
-            // ---- chunk level: the popped slot's chunk from the patched registers; the tail chunk incrementally
-            if (lane == (mi & 63)) mys.sum = __builtin_inff();
-            if (has1 && (s1 >> 6) == ck0 && lane == (s1 & 63)) mys = c1;
-            if (has2 && (s2 >> 6) == ck0 && lane == (s2 & 63)) mys = c2;
-            float cs0 = mys.sum;
-            int ci0 = ck0 * 64 + lane;
-            argmin_si(cs0, ci0, lane);
-            if (lane == 0) { PbEntry m; m.sum = cs0; m.pos = (unsigned)ci0; FL.set_cmin(ck0, m); }
-            if (ck0 == tail_ck) { tail_cs = cs0; tail_ci = ci0; }
-            // ---- super-chunk level, same scheme on the chunk minima (patched as the chunk level changes them)
-            if (lane == (ck0 & 63)) { myc.sum = cs0; myc.pos = (unsigned)ci0; }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bool has = u == 0 ? has1 : has2;
-                const int sl = u == 0 ? s1 : s2;
-                const float csum = u == 0 ? c1.sum : c2.sum;
-                if (!has) continue;
-                const int ck = sl >> 6;
-                if (ck != tail_ck) { tail_ck = ck; tail_cs = __builtin_inff(); tail_ci = 0x7FFFFFFF; }   // a new chunk starts
-                if (ck == ck0) continue;                                   // covered by the reduction above
-                if (csum < tail_cs) { tail_cs = csum; tail_ci = sl; }      // (a tie keeps the older, lower slot)
-                if (lane == 0) { PbEntry m; m.sum = tail_cs; m.pos = (unsigned)tail_ci; FL.set_cmin(ck, m); }
-                if ((ck >> 6) == sk0 && lane == (ck & 63)) { myc.sum = tail_cs; myc.pos = (unsigned)tail_ci; }
-            }
-            float ss0 = myc.sum;
-            int si0 = (int)myc.pos;
-            argmin_si(ss0, si0, lane);
-            if (lane == 0) { PbEntry m; m.sum = ss0; m.pos = (unsigned)si0; B.smin[sk0] = m; }
-            if (sk0 == tail_sk) { tail_ss = ss0; tail_si = si0; }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bool has = u == 0 ? has1 : has2;
-                const int sl = u == 0 ? s1 : s2;
-                const float csum = u == 0 ? c1.sum : c2.sum;
-                if (!has) continue;
-                const int sk = sl >> 12;
-                if (sk != tail_sk) { tail_sk = sk; tail_ss = __builtin_inff(); tail_si = 0x7FFFFFFF; }
-                if (sk == sk0) continue;
-                if (csum < tail_ss) { tail_ss = csum; tail_si = sl; }
-                if (lane == 0) { PbEntry m; m.sum = tail_ss; m.pos = (unsigned)tail_si; B.smin[sk] = m; }
-            }
-            wave_fence();
-            // promising-probability rule
-            const float rs = e.sum;
-            const float w1 = det_expf(P.c4 * rs) * spl, w2 = 1.0f - w1;
-            const float bt = __builtin_floorf((best - rs) / lrb_mean);
-            const int beta = bt > 0.0f ? (bt < 64.0f ? (int)bt : 64) : 0;
-            float bs = 0.0f;
-            bs = bs + w1 * (float)B.cdfA[beta];
-            bs = bs + w2 * (float)B.cdfH[beta];
-            if ((double)bs < p_t_pro) { stop = 1; ntep = j + 1; break; }
-            u64 D = S.d0 ^ L.P[p0], E = 1ull << p0;
-            if (ew > 1) { D ^= L.P[pA]; E |= 1ull << pA; }
-            if (ew > 2) { D ^= L.P[pB]; E |= 1ull << pB; }
-            const float cost = tep_cost(L, rs, D);
-            ++suc1;
-            if (cost < best) {
-                best = cost; bestD = D; bestE = E; bestidx = j + 1;
-                const float ratio = (1.0f - w1) / w1;
-                float prod = 1.0f;
-#pragma unroll 4
-                for (int p = 0; p < 64; ++p) {
-                    const float qp = B.q[64 + p];
-                    prod = prod * (((D >> p) & 1) ? 2.0f * qp : 2.0f * (1.0f - qp));
-                }
-                const float p_suc = 1.0f / (1.0f + ratio / prod);
-                ++suc2;
-                if ((double)p_suc > p_t_suc) { stop = 2; ntep = j + 1; break; }
-            }
-        }
-        search_finish(L, S, bestE, bestD, f, lane, cw_out);
-        if (lane == 0) {
-            if (metric_out) metric_out[f] = best;
-            if (best_out) best_out[f] = bestidx;
-            if (ntep_out) ntep_out[f] = ntep;
-            if (aux_out) { aux_out[f * 4] = cmp; aux_out[f * 4 + 1] = suc1; aux_out[f * 4 + 2] = suc2; aux_out[f * 4 + 3] = stop; }
-        }
-        wave_fence();
-    }
-}
-
 __global__ __launch_bounds__(256) void osd_counts_kernel(const u64 *__restrict__ cw, const u64 *__restrict__ label,
                                                          const int *__restrict__ index, const int *__restrict__ count,
                                                          const int *__restrict__ ntep, long long F,
@@ -867,23 +472,6 @@ __global__ __launch_bounds__(256) void osd_counts_kernel(const u64 *__restrict__
 // ---------------------------------------------------------------------------------------
 // context pieces: G columns, TEP table (order <= 3), front-end workspace
 // ---------------------------------------------------------------------------------------
-struct OsdState {
-    int64_t ntep[4] = {0, 0, 0, 0};
-    uchar4 *d_tep_fs = nullptr;       // FS visit order, weight classes 1..3 back to back
-    int *d_base2 = nullptr;           // order-2 ranks: number of index pairs with a larger sum
-    double *d_cdf_half = nullptr;     // PB-OSD: P[Bin(64, 1/2) <= b], b = 0..64
-    double *d_coef = nullptr;         // PB-OSD: (64-i)/(i+1)
-    void *d_pb_spill = nullptr;       // PB-OSD frontier overflow [waves][stride]
-    int *d_pb_queue = nullptr;        // PB-OSD frame hand-out counter
-    int64_t pb_spill_stride = 0;
-    int fs_off[4] = {0, 0, 0, 0}, fs_cnt[4] = {0, 0, 0, 0};
-    unsigned char *d_perm = nullptr;  // workspace [cap][128]
-    u64 *d_parity = nullptr;          // workspace [cap][64]
-    int64_t cap = 0;
-};
-
-static OsdState *state(ldpc_ctx *ctx) { return reinterpret_cast<OsdState *>(ctx->osd_state); }
-
 int osd_ctx_init(ldpc_ctx *ctx)
 {
     const ldpc_code &c = ctx->code;
@@ -948,9 +536,9 @@ int osd_ctx_init(ldpc_ctx *ctx)
         LDPC_HIP(hipMalloc((void **)&st->d_cdf_half, sizeof(cdf)));
         LDPC_HIP(hipMemcpy(st->d_cdf_half, cdf, sizeof(cdf), hipMemcpyHostToDevice));
         LDPC_HIP(hipMalloc((void **)&st->d_coef, sizeof(coef)));
-        LDPC_HIP(hipMalloc((void **)&st->d_pb_queue, sizeof(int)));
         LDPC_HIP(hipMemcpy(st->d_coef, coef, sizeof(coef), hipMemcpyHostToDevice));
     }
+    if (int rc = pb_ctx_init(ctx)) return rc;
     ctx->osd_ok = true;
     return LDPC_OK;
 }
@@ -960,31 +548,46 @@ void osd_ctx_release(ldpc_ctx *ctx)
     (void)hipFree(ctx->d_Gcols);
     (void)hipFree(ctx->d_tep);
     if (OsdState *st = state(ctx)) {
-        (void)hipFree(st->d_perm);
-        (void)hipFree(st->d_parity);
+        for (auto &kv : st->ws) {
+            (void)hipFree(kv.second.d_perm); (void)hipFree(kv.second.d_parity);
+            (void)hipFree(kv.second.d_pb_ctl); (void)hipFree(kv.second.d_pb_list); (void)hipFree(kv.second.d_pb_spill);
+        }
         (void)hipFree(st->d_tep_fs);
         (void)hipFree(st->d_base2);
         (void)hipFree(st->d_cdf_half);
         (void)hipFree(st->d_coef);
-        (void)hipFree(st->d_pb_spill);
-        (void)hipFree(st->d_pb_queue);
+        (void)hipFree(st->d_pb_tab);
         delete st;
     }
     ctx->osd_state = nullptr;
 }
 
-static int reserve(ldpc_ctx *ctx, int64_t frames)
+bool stream_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
+// the workspace of `s` with room for the front-end results of `frames` frames (0: just look it up);
+// allocation happens on a stream's first call or when a call outgrows it -- never while `s` is capturing
+static int stream_ws(ldpc_ctx *ctx, hipStream_t s, int64_t frames, StreamWs **out)
 {
     OsdState *st = state(ctx);
-    if (frames <= st->cap) return LDPC_OK;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)cs;
-    (void)hipFree(st->d_perm); (void)hipFree(st->d_parity);
-    st->d_perm = nullptr; st->d_parity = nullptr; st->cap = 0;
-    if (hipMalloc((void **)&st->d_perm, (size_t)frames * 128) != hipSuccess ||
-        hipMalloc((void **)&st->d_parity, (size_t)frames * 64 * sizeof(u64)) != hipSuccess)
-        return fail(LDPC_E_NOMEM, "OSD workspace for %lld frames could not be allocated", (long long)frames);
-    st->cap = frames;
+    std::lock_guard<std::mutex> lock(st->mu);
+    StreamWs &w = st->ws[s];
+    if (frames > 0 && frames < st->reserve_frames) frames = st->reserve_frames;
+    if (frames > w.cap) {
+        if (stream_capturing(s))
+            return fail(LDPC_E_NOMEM, "OSD workspace of this stream holds %lld frames, %lld needed: run one call (or "
+                        "ldpc_osd_reserve_stream) on the stream before capturing", (long long)w.cap, (long long)frames);
+        (void)hipFree(w.d_perm); (void)hipFree(w.d_parity);
+        w.d_perm = nullptr; w.d_parity = nullptr; w.cap = 0;
+        if (hipMalloc((void **)&w.d_perm, (size_t)frames * 128) != hipSuccess ||
+            hipMalloc((void **)&w.d_parity, (size_t)frames * 64 * sizeof(u64)) != hipSuccess)
+            return fail(LDPC_E_NOMEM, "OSD workspace for %lld frames could not be allocated", (long long)frames);
+        w.cap = frames;
+    }
+    *out = &w;
     return LDPC_OK;
 }
 
@@ -1006,7 +609,21 @@ int ldpc_osd_reserve(ldpc_ctx *ctx, int64_t max_frames)
 {
     if (!ctx || max_frames < 0) return fail(LDPC_E_ARG, "ldpc_osd_reserve: bad arguments");
     if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
-    return reserve(ctx, max_frames);
+    {
+        OsdState *st = state(ctx);
+        std::lock_guard<std::mutex> lock(st->mu);
+        if (max_frames > st->reserve_frames) st->reserve_frames = max_frames;
+    }
+    StreamWs *w;
+    return stream_ws(ctx, nullptr, max_frames, &w);   // the NULL stream's workspace now; other streams on their first call
+}
+
+int ldpc_osd_reserve_stream(ldpc_ctx *ctx, int64_t max_frames, void *stream)
+{
+    if (!ctx || max_frames < 0) return fail(LDPC_E_ARG, "ldpc_osd_reserve_stream: bad arguments");
+    if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
+    StreamWs *w;
+    return stream_ws(ctx, (hipStream_t)stream, max_frames, &w);
 }
 
 int ldpc_osd_ge(ldpc_ctx *ctx, const uint64_t *d_rows_in, int64_t F, uint64_t *d_rows_out, uint8_t *d_swaps,
@@ -1052,31 +669,7 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
 {
     OsdState *st = state(ctx);
     if (p->algo == LDPC_OSD_PB) {
-        const int64_t nmax = st->ntep[p->order];
-        const unsigned blocks = osd_grid(F) < 512 ? osd_grid(F) : 512;       // bounded: each wave owns a spill area
-        // the list is append-only: at most 1 + 2 (N_max - 1) slots; spilled slots first, spilled chunk minima after
-        const int64_t slots = 2 * nmax + 2;
-        if (slots > (int64_t)kPbSuper * 4096) return fail(LDPC_E_UNSUPPORTED, "ldpc_osd_decode: PB-OSD list of %lld slots exceeds the kernel's limit", (long long)slots);
-        const int64_t spill_slots = slots > kPbLdsSlots ? slots - kPbLdsSlots : 0;
-        const int64_t stride = spill_slots + (slots / 64 + 2) + 2;
-        if (stride > st->pb_spill_stride) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-                return fail(LDPC_E_NOMEM, "ldpc_osd_decode: PB-OSD frontier workspace must be sized before capturing (run one call first)");
-            (void)hipFree(st->d_pb_spill);
-            st->d_pb_spill = nullptr; st->pb_spill_stride = 0;
-            if (hipMalloc(&st->d_pb_spill, sizeof(PbEntry) * (size_t)stride * 512 * 4) != hipSuccess)
-                return fail(LDPC_E_NOMEM, "ldpc_osd_decode: PB-OSD frontier workspace (%lld entries per wave) could not be allocated", (long long)stride);
-            st->pb_spill_stride = stride;
-        }
-        PbParams pp;
-        pp.order = p->order; pp.nmax = (int)nmax; pp.cmin_off = spill_slots;
-        pp.c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)p->snr_db / 10.0)));    // -4 * noise_variance, pb_testing.py:50-52
-        LDPC_HIP(hipMemsetAsync(st->d_pb_queue, 0, sizeof(int), s));
-        hipLaunchKernelGGL(osd_pb_kernel, dim3(blocks), dim3(256), 0, s, d_y, d_index, d_count, (long long)F, d_perm,
-                           d_parity, pp, st->d_cdf_half, st->d_coef, reinterpret_cast<PbEntry *>(st->d_pb_spill),
-                           (long long)st->pb_spill_stride, st->d_pb_queue, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep,
-                           reinterpret_cast<int *>(p->d_aux));
+        return launch_pb(ctx, d_y, d_index, d_count, F, d_perm, d_parity, p, d_cw, d_metric, d_best, d_ntep, s);
     } else if (p->algo == LDPC_OSD_FS) {
         FsParams fp;
         fp.order = p->order; fp.quirk = p->fs_reference_quirk != 0;
@@ -1086,7 +679,7 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
         hipLaunchKernelGGL(osd_fs_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
                            d_perm, d_parity, st->d_tep_fs, fp, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
                            d_ntep);
-    } else if (p->order == 2 && !p->reserved) {
+    } else if (p->order == 2 && !(p->reserved & 1)) {
         hipLaunchKernelGGL(osd_search2_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
                            d_perm, d_parity, st->d_base2, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
     } else {   // table-driven scan: any order (and order 2 when params->reserved = 1, the cross-check path)
@@ -1124,18 +717,12 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
     int rc = check_params(ctx, p, "ldpc_osd_decode");
     if (rc) return rc;
     if (F == 0) return LDPC_OK;
-    OsdState *st = state(ctx);
-    if (F > st->cap) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-            return fail(LDPC_E_NOMEM, "ldpc_osd_decode: workspace holds %lld frames, %lld needed; call ldpc_osd_reserve before capturing", (long long)st->cap, (long long)F);
-        rc = reserve(ctx, F);
-        if (rc) return rc;
-    }
     hipStream_t s = (hipStream_t)stream;
+    StreamWs *w;
+    if ((rc = stream_ws(ctx, s, F, &w))) return rc;
     hipLaunchKernelGGL(osd_front_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
-                       reinterpret_cast<const u64 *>(ctx->d_Gcols), st->d_perm, st->d_parity, (int *)nullptr);
-    return launch_search(ctx, d_y, d_index, d_count, F, st->d_perm, st->d_parity, p, d_cw, d_metric, d_best, d_ntep, s);
+                       reinterpret_cast<const u64 *>(ctx->d_Gcols), w->d_perm, w->d_parity, (int *)nullptr);
+    return launch_search(ctx, d_y, d_index, d_count, F, w->d_perm, w->d_parity, p, d_cw, d_metric, d_best, d_ntep, s);
 }
 
 int ldpc_osd_counts(ldpc_ctx *ctx, const uint64_t *d_cw, const uint64_t *d_label_bits, const int32_t *d_index,

@@ -1,0 +1,921 @@
+// PB-OSD kernels for (128,64) codes on gfx950 (MI355X).
+//
+// Reference (paths relative to LDPC_128/): pb_osd, PB_OSD/pb_testing.py:100-149 -- best-first TEP generation
+// from a growing frontier list (optimal_tep_sequence :366-397: "first minimum of the reliability sums in list
+// order", pop, append <= 2 children) with two probabilistic stopping rules (acquire_prob_promising :448-461,
+// acquire_p_e_suc :423-436, thresholds :485-500).  All probabilities follow the float conventions of
+// oracle/ldpc_oracle.c orc_pb_osd: float32 with det_expf (IEEE + - * / only, host and device agree bit for
+// bit), float64 binomial-CDF recurrences, threshold comparisons in float64.
+//
+// The list is NOT replayed TEP by TEP (the round-1 kernel did that: one wavefront, ~1.2 us per TEP, 51 ms for
+// the rare frame on which no rule fires).  Three facts make the search batch-parallel and still exact
+// (tests/pb_chunk_model.py states the algorithm in NumPy and checks it against the literal oracle):
+//   1. every TEP has exactly one parent (extended child: e U {63}; adjacent child: largest index - 1), so the
+//      list never holds duplicates and the pop sequence visits each TEP of weight 1..order exactly once;
+//   2. a child's float32 sum is >= its parent's (monotone rounding), hence the pop sequence is the TEPs sorted
+//      by (sum, list slot), and slot(t) < slot(u) <=> parent(t) is popped before parent(u), or they share the
+//      parent and t is the extended child -- a comparator that only recurses when sums tie exactly;
+//   3. the stopping rules see the visit order only through "best so far", a prefix minimum.
+// So: a CHUNK of the visit order = all TEPs with sum in (lo, hi], sorted; its costs are evaluated in parallel and
+// the sequential rules are recovered with prefix scans and a "first stop" reduction.
+//
+//   pb_singles_kernel  one frame per wavefront: the pop sequence starts with the weight-1 TEPs {63}, {62}, ...
+//                      while |y'_p| < |y'_62| + |y'_63| (the smallest weight-2 sum); one TEP per lane.  About
+//                      half of the frames stop here at 2.5 dB; the others are appended to list A.
+//   pb_block_kernel    one frame of list A per workgroup, restarted from its first TEP: chunks chosen by value
+//                      thresholds (|y'_0|, then +inf) with per-weight-class candidate pruning, split by a
+//                      histogram when a threshold holds more than CAP TEPs; bitonic sort in LDS; exact tie
+//                      repair; parallel evaluation.  Frames whose sums tie massively (quantised inputs) are
+//                      appended to list B.
+//   pb_seq_kernel      the literal list replay (round-1 kernel) for list B.
+#include <math.h>
+
+#include "ldpc_internal.h"
+#include "ldpc_wave.h"
+#include "ldpc_search.h"
+#include "ldpc_osd_state.h"
+
+namespace ldpc {
+
+__device__ __forceinline__ float det_expf(float x)
+{
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) return 0.0f;
+    const float kf = __builtin_floorf(x * 1.44269504f + 0.5f);
+    const float r = (x - kf * 0.693359375f) - kf * -2.12194440e-4f;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    const float e = (p * (r * r) + r) + 1.0f;
+    return e * __int_as_float(((int)kf + 127) << 23);
+}
+
+// Frontier = the reference's growing TEP list (optimal_tep_sequence :366-397) kept in INSERTION order:
+// a popped entry is tombstoned in place (sum = +inf), children are appended, so "first minimum in list
+// order" is the arg-min on (sum, slot).  A search that never stops visits all N_max TEPs with a list of
+// tens of thousands of entries, so the arg-min is kept hierarchical: cmin[c] = best (sum, slot) of the 64
+// slots of chunk c, smin[s] = best of the 64 chunks of super-chunk s.  A pop reads the <= 32 super-minima,
+// then re-reduces one chunk and one super-chunk: ~3 wave reductions per TEP whatever the list length.
+// Slots < kPbLdsSlots and chunk minima < kPbLdsChunks live in LDS, the rest in a per-wave global area.
+struct PbEntry {
+    float sum;          // reliability sum of the flipped MRB positions (ascending, sequential); +inf = removed
+    unsigned pos;       // slots: pos0 | pos1 << 8 | pos2 << 16 | weight << 24;  minima: slot index
+};
+constexpr int kPbLdsSlots = 512, kPbLdsChunks = 64, kPbSuper = 32;   // 32 super-chunks x 4096 slots >= 2 N_max (order 3)
+
+struct __attribute__((aligned(16))) PbLds {
+    double cdfA[65];             // P[Bin(64, p1) <= b]
+    double cdfH[65];             // P[Bin(64, 1/2) <= b] (copied once per wavefront: a global read per TEP sat on the critical path)
+    float q[128];                // sigmoid(c4 |y'_p|)
+    PbEntry fr[kPbLdsSlots];     // head of the list
+    PbEntry cmin[kPbLdsChunks];  // chunk minima of the first 4096 slots
+    PbEntry smin[kPbSuper];      // super-chunk minima
+};
+
+struct PbParams {
+    int order, nmax;
+    float c4;
+    long long cmin_off;          // offset of the spilled chunk minima inside a wave's global area
+};
+
+struct PbList {
+    PbLds *B;
+    PbEntry *spill;              // slots >= kPbLdsSlots, then chunk minima >= kPbLdsChunks at cmin_off
+    long long cmin_off;
+    __device__ __forceinline__ PbEntry slot(int i) const { return i < kPbLdsSlots ? B->fr[i] : spill[i - kPbLdsSlots]; }
+    __device__ __forceinline__ void set_slot(int i, PbEntry e) const { if (i < kPbLdsSlots) B->fr[i] = e; else spill[i - kPbLdsSlots] = e; }
+    __device__ __forceinline__ PbEntry cmin(int c) const { return c < kPbLdsChunks ? B->cmin[c] : spill[cmin_off + c - kPbLdsChunks]; }
+    __device__ __forceinline__ void set_cmin(int c, PbEntry e) const { if (c < kPbLdsChunks) B->cmin[c] = e; else spill[cmin_off + c - kPbLdsChunks] = e; }
+};
+
+// wave arg-min on (sum, index): lower index wins ties; result in every lane
+__device__ __forceinline__ void argmin_si(float &s, int &idx, int lane)
+{
+    const float m = wave_min_f32(s);
+    idx = wave_min_i32(s == m ? idx : 0x7FFFFFFF);
+    s = m;
+}
+
+
+// per-frame PB quantities (wave-uniform), float conventions of the oracle
+struct PbFrame {
+    float spl, lrb_mean;       // prod (1 - q_p) over the MRB (com_mrb_prob :35-41), mean |y'| over the LRB (:401)
+    double p_t_suc, p_t_pro;   // calculate_two_thresholds :485-500
+};
+
+// One wavefront: q[p] = sigmoid(c4 |y'_p|), the binomial CDF table of the mean LRB error probability and
+// the two thresholds.  L.w must be in place; q / cdfA are per-frame LDS arrays.
+__device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, double *cdfA, const double *__restrict__ coef,
+                                                  float c4, int order, int nmax, int lane)
+{
+    q[lane] = 1.0f / (1.0f + det_expf(-(c4 * L.w[lane])));
+    q[lane + 64] = 1.0f / (1.0f + det_expf(-(c4 * L.w[lane + 64])));
+    wave_fence();
+    // sequential (ascending position) means / product, as the oracle defines them
+    float a1 = 0.0f, aw = 0.0f, at = 0.0f, spl = 1.0f;
+#pragma unroll 4
+    for (int p = 0; p < 64; ++p) {
+        a1 = a1 + q[64 + p];
+        aw = aw + L.w[64 + p];
+        at = at + q[p];
+        spl = spl * (1.0f - q[p]);
+    }
+    const float p1 = a1 / 64.0f, lrb_mean = aw / 64.0f, pt = at / 64.0f;
+    // binomial CDF tables by the pmf recurrence (float64): full table for p1, up to `order` for pt
+    double niu;
+    {
+        double qq = 1.0 - (double)p1, t = qq;
+        for (int s = 0; s < 6; ++s) t = t * t;
+        const double ratio = (double)p1 / qq;
+        double acc = t;
+        if (lane == 0) cdfA[0] = acc;
+#pragma unroll 2
+        for (int i = 0; i < 64; ++i) {
+            t = t * coef[i] * ratio;
+            acc = acc + t;
+            if (lane == 0) cdfA[i + 1] = acc;
+        }
+        qq = 1.0 - (double)pt; t = qq;
+        for (int s = 0; s < 6; ++s) t = t * t;
+        const double ratio2 = (double)pt / qq;
+        acc = t;
+        for (int i = 0; i < order; ++i) { t = t * coef[i] * ratio2; acc = acc + t; }
+        niu = acc;
+    }
+    PbFrame F;
+    F.spl = spl; F.lrb_mean = lrb_mean;
+    F.p_t_suc = 0.99 * niu;
+    F.p_t_pro = 0.002 * __builtin_sqrt((1.0 - niu) / (double)nmax);
+    wave_fence();
+    return F;
+}
+
+// promising-probability rule (acquire_prob_promising :448-461): true = stop
+__device__ __forceinline__ bool pb_not_promising(float rs, float best, const PbFrame &F, float c4, const double *cdfA,
+                                                 const double *cdfH, float &w1_out)
+{
+    const float w1 = det_expf(c4 * rs) * F.spl, w2 = 1.0f - w1;
+    const float bt = __builtin_floorf((best - rs) / F.lrb_mean);
+    const int beta = bt > 0.0f ? (bt < 64.0f ? (int)bt : 64) : 0;
+    float bs = 0.0f;
+    bs = bs + w1 * (float)cdfA[beta];
+    bs = bs + w2 * (float)cdfH[beta];
+    w1_out = w1;
+    return (double)bs < F.p_t_pro;
+}
+
+// success rule (acquire_p_e_suc :423-436) for a candidate that became the best: true = stop
+__device__ __forceinline__ bool pb_success(u64 D, float w1, const float *q, const PbFrame &F)
+{
+    const float ratio = (1.0f - w1) / w1;
+    float prod = 1.0f;
+#pragma unroll 4
+    for (int p = 0; p < 64; ++p) {
+        const float qp = q[64 + p];
+        prod = prod * (((D >> p) & 1) ? 2.0f * qp : 2.0f * (1.0f - qp));
+    }
+    const float p_suc = 1.0f / (1.0f + ratio / prod);
+    return (double)p_suc > F.p_t_suc;
+}
+
+// ---------------------------------------------------------------------------------------
+// TEP table of the chunk kernels: ids 0..63 = {63 - id}; ids 64..2079 = pairs, 2080..43743 = triples, each
+// class by DESCENDING smallest position, so "all positions >= a" is a prefix of every class.
+// ---------------------------------------------------------------------------------------
+constexpr int kPbPairs0 = 64, kPbTriples0 = 64 + 2016, kPbTabSize = 64 + 2016 + 41664;
+
+struct PbTep {
+    int p0, p1, p2, wt;
+};
+__device__ __forceinline__ PbTep pb_tep(const uchar4 *__restrict__ tab, int id)
+{
+    const uchar4 t = tab[id];
+    return PbTep{t.x, t.y, t.z, t.w};
+}
+__device__ __forceinline__ float pb_sum(const float *w, const PbTep &t)
+{
+    float s = w[t.p0];
+    if (t.wt > 1) s = s + w[t.p1];
+    if (t.wt > 2) s = s + w[t.p2];
+    return s;
+}
+__device__ __forceinline__ int pb_last(const PbTep &t) { return t.wt == 1 ? t.p0 : (t.wt == 2 ? t.p1 : t.p2); }
+// children pushed by a pop minus the popped entry itself (optimal_tep_sequence :381-396)
+__device__ __forceinline__ int pb_delta(const PbTep &t, int order)
+{
+    const int last = pb_last(t), prev = t.wt == 2 ? t.p0 : t.p1;
+    const int has1 = last < 63 && t.wt < order;
+    const int has2 = t.wt > 1 ? (last - prev > 1) : (last - 1 > -1);
+    return has1 + has2 - 1;
+}
+// t := parent(t); returns 0 = t was the extended child, 1 = the adjacent child, -1 = t is the root {63}
+__device__ __forceinline__ int pb_to_parent(PbTep &t)
+{
+    const int last = pb_last(t);
+    if (last == 63) {
+        if (t.wt == 1) return -1;
+        --t.wt;
+        return 0;
+    }
+    if (t.wt == 1) t.p0 = last + 1; else if (t.wt == 2) t.p1 = last + 1; else t.p2 = last + 1;
+    return 1;
+}
+__device__ __forceinline__ bool pb_same(const PbTep &a, const PbTep &b)
+{
+    return a.wt == b.wt && a.p0 == b.p0 && (a.wt < 2 || a.p1 == b.p1) && (a.wt < 3 || a.p2 == b.p2);
+}
+// t is popped before u (t != u): (sum, list slot) order, the slot order through the parents
+__device__ bool pb_visit_less(const float *w, PbTep t, PbTep u)
+{
+    for (;;) {
+        const float st = pb_sum(w, t), su = pb_sum(w, u);
+        if (st != su) return st < su;
+        const int kt = pb_to_parent(t), ku = pb_to_parent(u);
+        if (kt < 0) return true;
+        if (ku < 0) return false;
+        if (pb_same(t, u)) return kt < ku;
+    }
+}
+__device__ __forceinline__ void pb_apply(const SearchLds &L, const PbTep &t, u64 d0, u64 &D, u64 &E)
+{
+    D = d0 ^ L.P[t.p0]; E = 1ull << t.p0;
+    if (t.wt > 1) { D ^= L.P[t.p1]; E |= 1ull << t.p1; }
+    if (t.wt > 2) { D ^= L.P[t.p2]; E |= 1ull << t.p2; }
+}
+
+struct PbOut {
+    u64 *cw; float *metric; int *best, *ntep, *aux;
+};
+__device__ __forceinline__ void pb_write(SearchLds &L, const SearchFrame &S, const PbOut &O, long long f, int lane, u64 bestE,
+                                         u64 bestD, float best, int bestidx, int ntep, int cmp, int suc1, int suc2, int stop)
+{
+    search_finish(L, S, bestE, bestD, f, lane, O.cw);
+    if (lane == 0) {
+        if (O.metric) O.metric[f] = best;
+        if (O.best) O.best[f] = bestidx;
+        if (O.ntep) O.ntep[f] = ntep;
+        if (O.aux) { O.aux[f * 4] = cmp; O.aux[f * 4 + 1] = suc1; O.aux[f * 4 + 2] = suc2; O.aux[f * 4 + 3] = stop; }
+    }
+    wave_fence();
+}
+
+// inclusive wave scans (lane order)
+__device__ __forceinline__ float wave_incl_min(float v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const float t = __shfl_up(v, off, 64); if (lane >= off) v = __builtin_fminf(v, t); }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_add(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// stage 1: the weight-1 head of the pop sequence, one frame per wavefront, one TEP per lane
+//   mode 0: normal; 1: every frame straight to list A (block kernel); 2: every frame to list B (list replay)
+// ---------------------------------------------------------------------------------------
+struct PbSinglesLds {
+    SearchLds s;
+    double cdfA[65], cdfH[65];
+    float q[128];
+};
+
+__global__ __launch_bounds__(256) void pb_singles_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                         const int *__restrict__ count, long long F,
+                                                         const unsigned char *__restrict__ perm_in,
+                                                         const u64 *__restrict__ parity_in, PbParams P, int mode,
+                                                         const double *__restrict__ cdf_half, const double *__restrict__ coef,
+                                                         int *__restrict__ ctl, int *__restrict__ listA, int *__restrict__ listB,
+                                                         PbOut O)
+{
+    __shared__ PbSinglesLds lds[4];
+    const int lane = threadIdx.x & 63;
+    PbSinglesLds &W = lds[threadIdx.x >> 6];
+    SearchLds &L = W.s;
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (mode != 0) {   // hand every frame on, in frame order
+        for (long long f = wave * 64 + lane; f < nframes; f += (long long)gridDim.x * 256) (mode == 1 ? listA : listB)[f] = (int)f;
+        if (wave == 0 && lane == 0) ctl[mode == 1 ? 1 : 3] = (int)nframes;
+        return;
+    }
+    W.cdfH[lane] = cdf_half[lane];
+    if (lane == 0) W.cdfH[64] = cdf_half[64];
+    wave_fence();
+    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+        const long long src = index ? index[f] : f;
+        const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+        const PbFrame Fr = pb_frame_setup(L, W.q, W.cdfA, coef, P.c4, P.order, P.nmax, lane);
+        const float best0 = tep_cost(L, 0.0f, S.d0);
+        // lane l <-> TEP {63 - l}, visit index l; valid while its weight is below the smallest weight-2 sum
+        const int p = 63 - lane;
+        const float rs = L.w[p];
+        const float s2min = L.w[62] + L.w[63];
+        const u64 vmask = __ballot(P.order == 1 || rs < s2min);
+        const int nhead = (~vmask) ? __builtin_ctzll(~vmask) : 64;
+        const bool valid = lane < nhead;
+        const u64 D = S.d0 ^ L.P[p];
+        const float cost = valid ? tep_cost(L, rs, D) : __builtin_inff();
+        const float incl = wave_incl_min(cost, lane);
+        float before = __shfl_up(incl, 1, 64);
+        before = lane == 0 ? best0 : __builtin_fminf(before, best0);
+        float w1;
+        const bool stop1 = valid && pb_not_promising(rs, before, Fr, P.c4, W.cdfA, W.cdfH, w1);
+        const bool newbest = valid && cost < before;
+        bool stop2 = false;
+        if (newbest) stop2 = pb_success(D, w1, W.q, Fr);
+        const u64 sm = __ballot(stop1 || stop2);
+        if (sm == 0 && P.order > 1) {   // no rule fired on the head: the block kernel takes the frame
+            if (lane == 0) listA[atomicAdd(&ctl[1], 1)] = (int)f;
+            continue;
+        }
+        const int ls = sm ? __builtin_ctzll(sm) : 63;                 // (order 1 without a stop: all 64 TEPs visited)
+        const int reason = sm ? (((__ballot(stop1) >> ls) & 1) ? 1 : 2) : 0;
+        const int npop = ls + 1;
+        const int nev = reason == 1 ? ls : ls + 1;
+        const u64 nbm = __ballot(newbest) & (nev >= 64 ? ~0ull : ((1ull << nev) - 1));
+        float best = best0;
+        u64 bestD = S.d0, bestE = 0;
+        int bestidx = 0;
+        if (nbm) {
+            const int lb = 63 - __builtin_clzll(nbm);
+            best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cost), lb));
+            bestD = readlane64(D, lb);
+            bestE = 1ull << (63 - lb);
+            bestidx = lb + 1;
+        }
+        // frontier sizes before the pops: 1, 1, 2, 3, ... (order > 1) or always 1 (order 1)
+        const int ones = P.order > 1 ? (npop < 2 ? npop : 2) : npop;
+        pb_write(L, S, O, f, lane, bestE, bestD, best, bestidx, sm ? npop : P.nmax, 2 * npop - ones, nev, __popcll(nbm), reason);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// stage 2: one frame per workgroup, sorted chunks
+// ---------------------------------------------------------------------------------------
+constexpr int kPbBins = 1024, kPbMaxTie = 16;
+
+template <int NT, int CAP>
+struct __attribute__((aligned(16))) PbBlockLds {
+    SearchLds s;
+    double cdfA[65], cdfH[65];
+    float q[128];
+    u64 keys[CAP];          // (sum bits << 32) | table id
+    float cost[CAP];
+    int hist[kPbBins];
+    float red_f[2][NT / 64];
+    int red_i[2][NT / 64];
+    PbFrame fr;
+    // uniform search state
+    float lo, hi_cur, best;
+    int theta_i, j, nlive, cmp, suc1, suc2, bestidx;
+    u64 bestD, bestE, d0;
+    // per-chunk scratch
+    int nkeys, bstar, degenerate, gstop, reason, ones, nev, nnb, lnb, ticket;
+};
+
+// candidate prefix lengths of the three weight classes for the sum bound `hi` (all TEPs with sum <= hi have
+// their smallest position in the prefix; the slack terms cover the roundings of the float32 sums)
+__device__ __forceinline__ void pb_candidates(const SearchLds &L, float hi, int order, int lane, int &n1, int &n2, int &n3)
+{
+    const float wl = L.w[lane];
+    const float w63 = L.w[63], w6263 = L.w[62] + L.w[63];
+    const bool inf = !(hi < __builtin_inff());
+    const float h2 = (hi - w63) + hi * 9.5367431640625e-7f;       // 2^-20
+    const float h3 = (hi - w6263) + hi * 1.9073486328125e-6f;     // 2^-19
+    const u64 m1 = __ballot(inf || wl <= hi), m2 = __ballot(inf || wl <= h2), m3 = __ballot(inf || wl <= h3);
+    const int c1 = m1 ? 64 - __builtin_ctzll(m1) : 0, c2 = m2 ? 64 - __builtin_ctzll(m2) : 0, c3 = m3 ? 64 - __builtin_ctzll(m3) : 0;
+    n1 = c1;
+    n2 = order > 1 ? c2 * (c2 - 1) / 2 : 0;
+    n3 = order > 2 ? c3 * (c3 - 1) * (c3 - 2) / 6 : 0;
+}
+
+__device__ __forceinline__ void pb_cand(const uchar4 *__restrict__ tab, const float *w, int i, int n1, int n2, int &id, float &sum)
+{
+    if (i < n1) { id = i; sum = w[63 - i]; }
+    else if (i < n1 + n2) { id = kPbPairs0 + (i - n1); const uchar4 t = tab[id]; sum = w[t.x] + w[t.y]; }
+    else { id = kPbTriples0 + (i - n1 - n2); const uchar4 t = tab[id]; sum = (w[t.x] + w[t.y]) + w[t.z]; }
+}
+
+template <int NT, int CAP>
+__global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                      const unsigned char *__restrict__ perm_in,
+                                                      const u64 *__restrict__ parity_in, PbParams P,
+                                                      const double *__restrict__ cdf_half, const double *__restrict__ coef,
+                                                      const uchar4 *__restrict__ tab, int *__restrict__ ctl,
+                                                      const int *__restrict__ listA, int *__restrict__ listB, PbOut O)
+{
+    constexpr int W = NT / 64;
+    __shared__ PbBlockLds<NT, CAP> B;
+    SearchLds &L = B.s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nlist = ctl[1];
+    if (tid < 65) B.cdfH[tid] = cdf_half[tid];
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) B.ticket = atomicAdd(&ctl[2], 1);
+        __syncthreads();
+        const int tk = B.ticket;
+        if (tk >= nlist) break;
+        const long long f = listA[tk];
+        const long long src = index ? index[f] : f;
+        SearchFrame S{};
+        if (wave == 0) S = search_prepare_regs<false>(L, y, src, perm_in[f * 128 + lane], perm_in[f * 128 + 64 + lane], parity_in[f * 64 + lane], lane);
+        __syncthreads();
+        // byte LUTs: two per wavefront (W = 4), |y'| is in place
+        for (int b = wave; b < 8; b += W) build_byte_luts<1>(L.lut + b, &L.w[64 + 8 * b], lane);
+        if (wave == 0) {
+            const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, coef, P.c4, P.order, P.nmax, lane);
+            if (lane == 0) {
+                B.fr = Fr; B.d0 = S.d0;
+                B.lo = -1.0f; B.theta_i = 0; B.hi_cur = L.w[0];
+                B.j = 0; B.nlive = 1; B.cmp = 0; B.suc1 = 0; B.suc2 = 0; B.bestidx = 0;
+                B.bestD = S.d0; B.bestE = 0; B.degenerate = 0;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) B.best = tep_cost(L, 0.0f, B.d0);
+        __syncthreads();
+        const PbFrame Fr = B.fr;
+        const u64 d0 = B.d0;
+        int stop = 0, ntep = P.nmax;
+
+        for (;;) {   // one chunk of the visit order per trip
+            const float lo = B.lo, hi = B.hi_cur;
+            const int theta_i = B.theta_i;
+            const float theta = theta_i == 0 ? L.w[0] : __builtin_inff();
+            int n1, n2, n3;
+            pb_candidates(L, hi, P.order, lane, n1, n2, n3);
+            const int total = n1 + n2 + n3;
+            // ---- pass A: how many TEPs in (lo, hi], smallest and largest sum
+            int cnt = 0;
+            float mn = __builtin_inff(), mx = -1.0f;
+            for (int i = tid; i < total; i += NT) {
+                int id; float s;
+                pb_cand(tab, L.w, i, n1, n2, id, s);
+                if (s > lo && s <= hi) { ++cnt; mn = __builtin_fminf(mn, s); mx = __builtin_fmaxf(mx, s); }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                cnt += __shfl_xor(cnt, off, 64);
+                mn = __builtin_fminf(mn, __shfl_xor(mn, off, 64));
+                mx = __builtin_fmaxf(mx, __shfl_xor(mx, off, 64));
+            }
+            if (lane == 0) { B.red_i[0][wave] = cnt; B.red_f[0][wave] = mn; B.red_f[1][wave] = mx; }
+            __syncthreads();
+            cnt = 0; mn = __builtin_inff(); mx = -1.0f;
+#pragma unroll
+            for (int w = 0; w < W; ++w) { cnt += B.red_i[0][w]; mn = __builtin_fminf(mn, B.red_f[0][w]); mx = __builtin_fmaxf(mx, B.red_f[1][w]); }
+            __syncthreads();
+            if (cnt == 0) {
+                if (hi < theta) { if (tid == 0) { B.lo = hi; B.hi_cur = theta; } }
+                else if (theta_i == 1) break;                                    // every TEP visited, no rule fired
+                else if (tid == 0) { B.lo = lo > theta ? lo : theta; B.theta_i = 1; B.hi_cur = __builtin_inff(); }
+                __syncthreads();
+                continue;
+            }
+            const bool use_hist = cnt > CAP;
+            float scale = 0.0f;
+            if (use_hist) {
+                if (!(mn < mx)) { if (tid == 0) B.degenerate = 1; __syncthreads(); break; }   // > CAP equal sums
+                scale = (float)kPbBins / (mx - mn);
+                for (int b = tid; b < kPbBins; b += NT) B.hist[b] = 0;
+                __syncthreads();
+                for (int i = tid; i < total; i += NT) {
+                    int id; float s;
+                    pb_cand(tab, L.w, i, n1, n2, id, s);
+                    if (s > lo && s <= hi) {
+                        const int bin = (int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1));
+                        atomicAdd(&B.hist[bin], 1);
+                    }
+                }
+                __syncthreads();
+                // largest bin whose cumulative count still fits the chunk
+                constexpr int PERB = kPbBins / NT;
+                int local = 0;
+#pragma unroll
+                for (int q = 0; q < PERB; ++q) local += B.hist[tid * PERB + q];
+                const int incl = wave_incl_add(local, lane);
+                if (lane == 63) B.red_i[0][wave] = incl;
+                __syncthreads();
+                int run = incl - local;
+                for (int w = 0; w < wave; ++w) run += B.red_i[0][w];
+                int mybest = -1;
+#pragma unroll
+                for (int q = 0; q < PERB; ++q) { run += B.hist[tid * PERB + q]; if (run <= CAP) mybest = tid * PERB + q; }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { const int t = __shfl_xor(mybest, off, 64); mybest = t > mybest ? t : mybest; }
+                if (lane == 0) B.red_i[1][wave] = mybest;
+                __syncthreads();
+                int bstar = -1;
+#pragma unroll
+                for (int w = 0; w < W; ++w) bstar = B.red_i[1][w] > bstar ? B.red_i[1][w] : bstar;
+                __syncthreads();
+                if (bstar < 0) {   // the first bin alone is too large: zoom into it
+                    if (tid == 0) B.hi_cur = mn + (mx - mn) * (1.0f / (float)kPbBins);
+                    __syncthreads();
+                    continue;
+                }
+                if (tid == 0) B.bstar = bstar;
+            }
+            // ---- gather the chunk
+            if (tid == 0) B.nkeys = 0;
+            __syncthreads();
+            const int bstar = use_hist ? B.bstar : kPbBins;
+            for (int i = tid; i < total; i += NT) {
+                int id; float s;
+                pb_cand(tab, L.w, i, n1, n2, id, s);
+                bool sel = s > lo && s <= hi;
+                if (sel && use_hist) sel = (int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1)) <= bstar;
+                if (sel) B.keys[atomicAdd(&B.nkeys, 1)] = ((u64)__float_as_uint(s) << 32) | (unsigned)id;
+            }
+            __syncthreads();
+            const int n = B.nkeys;
+            int npow = 2;
+            while (npow < n) npow <<= 1;
+            for (int i = n + tid; i < npow; i += NT) B.keys[i] = ~0ull;
+            __syncthreads();
+            // ---- bitonic sort, ascending
+            for (int k = 2; k <= npow; k <<= 1)
+                for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                    for (int i = tid; i < (npow >> 1); i += NT) {
+                        const int a = ((i & ~(jj - 1)) << 1) | (i & (jj - 1)), b = a | jj;
+                        const u64 x = B.keys[a], yv = B.keys[b];
+                        if ((x > yv) == ((a & k) == 0)) { B.keys[a] = yv; B.keys[b] = x; }
+                    }
+                    __syncthreads();
+                }
+            // ---- equal sums: list order (pb_visit_less); one thread per run of equal sums
+            for (int i = tid; i + 1 < n; i += NT) {
+                const unsigned si = (unsigned)(B.keys[i] >> 32);
+                if ((i == 0 || (unsigned)(B.keys[i - 1] >> 32) != si) && (unsigned)(B.keys[i + 1] >> 32) == si) {
+                    int g = 2;
+                    while (i + g < n && g <= kPbMaxTie && (unsigned)(B.keys[i + g] >> 32) == si) ++g;
+                    if (g > kPbMaxTie) { B.degenerate = 1; continue; }
+                    for (int a = 1; a < g; ++a) {
+                        const u64 ka = B.keys[i + a];
+                        const PbTep ta = pb_tep(tab, (int)(unsigned)ka);
+                        int b = a;
+                        while (b > 0 && pb_visit_less(L.w, ta, pb_tep(tab, (int)(unsigned)B.keys[i + b - 1]))) { B.keys[i + b] = B.keys[i + b - 1]; --b; }
+                        B.keys[i + b] = ka;
+                    }
+                }
+            }
+            if (tid == 0) { B.gstop = 0x7FFFFFFF; B.reason = 0; B.ones = 0; B.nev = 0; B.nnb = 0; B.lnb = -1; }
+            __syncthreads();
+            if (B.degenerate) break;
+            // ---- evaluate: thread t owns the entries [t per, (t+1) per) of the sorted chunk
+            const int per = (n + NT - 1) / NT;
+            const int i0 = tid * per, i1 = (i0 + per) < n ? (i0 + per) : n;
+            float tmin = __builtin_inff();
+            int tdel = 0;
+            for (int i = i0; i < i1; ++i) {
+                const u64 key = B.keys[i];
+                const PbTep t = pb_tep(tab, (int)(unsigned)key);
+                u64 D, E;
+                pb_apply(L, t, d0, D, E);
+                const float c = tep_cost(L, __uint_as_float((unsigned)(key >> 32)), D);
+                B.cost[i] = c;
+                tmin = __builtin_fminf(tmin, c);
+                tdel += pb_delta(t, P.order);
+            }
+            // exclusive scans over the threads: min of the costs / sum of the frontier growth before my entries
+            const float imin = wave_incl_min(tmin, lane);
+            const int iadd = wave_incl_add(tdel, lane);
+            if (lane == 63) { B.red_f[0][wave] = imin; B.red_i[0][wave] = iadd; }
+            __syncthreads();
+            float before = __shfl_up(imin, 1, 64);
+            if (lane == 0) before = __builtin_inff();
+            int nlb = iadd - tdel, tot_del = 0;
+            for (int w = 0; w < W; ++w) {
+                if (w < wave) { before = __builtin_fminf(before, B.red_f[0][w]); nlb += B.red_i[0][w]; }
+                tot_del += B.red_i[0][w];
+            }
+            before = __builtin_fminf(before, B.best);
+            nlb += B.nlive;
+            // ---- the sequential rules on my entries, assuming no earlier stop
+            int ones = 0, nev = 0, nnb = 0, lnb = -1, lstop = 0x7FFFFFFF, lreason = 0;
+            for (int i = i0; i < i1; ++i) {
+                const u64 key = B.keys[i];
+                const float rs = __uint_as_float((unsigned)(key >> 32)), c = B.cost[i];
+                const PbTep t = pb_tep(tab, (int)(unsigned)key);
+                ones += nlb == 1;
+                nlb += pb_delta(t, P.order);
+                float w1;
+                if (pb_not_promising(rs, before, Fr, P.c4, B.cdfA, B.cdfH, w1)) { lstop = i; lreason = 1; break; }
+                ++nev;
+                if (c < before) {
+                    before = c; lnb = i; ++nnb;
+                    u64 D, E;
+                    pb_apply(L, t, d0, D, E);
+                    if (pb_success(D, w1, B.q, Fr)) { lstop = i; lreason = 2; break; }
+                }
+            }
+            if (lstop != 0x7FFFFFFF) atomicMin(&B.gstop, lstop);
+            __syncthreads();
+            const int gstop = B.gstop;
+            if (i0 < i1 && i0 <= gstop) {     // my entries lie before (or contain) the first stop: they count
+                atomicAdd(&B.ones, ones); atomicAdd(&B.nev, nev); atomicAdd(&B.nnb, nnb);
+                if (lnb >= 0) atomicMax(&B.lnb, lnb);
+                if (lstop == gstop) B.reason = lreason;
+            }
+            __syncthreads();
+            if (lnb >= 0 && lnb == B.lnb && i0 <= gstop) {   // the last improvement before the stop is mine
+                const PbTep t = pb_tep(tab, (int)(unsigned)B.keys[lnb]);
+                u64 D, E;
+                pb_apply(L, t, d0, D, E);
+                B.best = B.cost[lnb]; B.bestD = D; B.bestE = E; B.bestidx = B.j + lnb + 1;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const int npop = gstop != 0x7FFFFFFF ? gstop + 1 : n;
+                B.cmp += 2 * npop - B.ones; B.suc1 += B.nev; B.suc2 += B.nnb;
+            }
+            if (gstop != 0x7FFFFFFF) { stop = B.reason; ntep = B.j + gstop + 1; __syncthreads(); break; }
+            if (tid == 0) {
+                B.j += n; B.nlive += tot_del;
+                if (use_hist) B.lo = __uint_as_float((unsigned)(B.keys[n - 1] >> 32));
+                else { B.lo = hi; if (hi < theta) B.hi_cur = theta; }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        if (B.degenerate) {   // massive ties: the literal list replay decodes this frame
+            if (tid == 0) listB[atomicAdd(&ctl[3], 1)] = (int)f;
+            continue;
+        }
+        if (wave == 0)
+            pb_write(L, S, O, f, lane, B.bestE, B.bestD, B.best, B.bestidx, ntep, B.cmp, B.suc1, B.suc2, stop);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// stage 3: literal replay of the frontier list, one frame of list B per wavefront (frames whose sums tie
+// massively, or every frame when the caller asks for this path as a cross-check)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pb_seq_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                     const unsigned char *__restrict__ perm_in,
+                                                     const u64 *__restrict__ parity_in, PbParams P,
+                                                     const double *__restrict__ cdf_half, const double *__restrict__ coef,
+                                                     PbEntry *__restrict__ spill_all, long long spill_stride,
+                                                     int *__restrict__ ctl, const int *__restrict__ listB, PbOut O)
+{
+    __shared__ SearchLds lds[4];
+    __shared__ PbLds pbl[4];
+    const int lane = threadIdx.x & 63;
+    SearchLds &L = lds[threadIdx.x >> 6];
+    PbLds &B = pbl[threadIdx.x >> 6];
+    const int nlist = ctl[3];
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    PbEntry *spill = spill_all + wave * spill_stride;
+    B.cdfH[lane] = cdf_half[lane];
+    if (lane == 0) B.cdfH[64] = cdf_half[64];
+    wave_fence();
+
+    // frames are handed out through a device counter: run times differ by orders of magnitude between frames
+    for (;;) {
+        int fq = 0;
+        if (lane == 0) fq = atomicAdd(&ctl[4], 1);
+        const int tk = __builtin_amdgcn_readfirstlane(fq);
+        if (tk >= nlist) break;
+        const long long f = listB[tk];
+        const long long src = index ? index[f] : f;
+        const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+        const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, coef, P.c4, P.order, P.nmax, lane);
+        const float spl = Fr.spl, lrb_mean = Fr.lrb_mean;
+        const double p_t_suc = Fr.p_t_suc, p_t_pro = Fr.p_t_pro;
+        if (lane == 0) {   // starting point: the single TEP {k-1} (pb_testing.py:109-110)
+            PbEntry e0; e0.sum = L.w[63]; e0.pos = 63u | (1u << 24); B.fr[0] = e0;
+            PbEntry m0; m0.sum = e0.sum; m0.pos = 0; B.cmin[0] = m0; B.smin[0] = m0;
+        }
+        wave_fence();
+        int nused = 1, nlive = 1, ntep = P.nmax, bestidx = 0, stop = 0, cmp = 0, suc1 = 0, suc2 = 0;
+        int tail_ck = 0, tail_ci = 0, tail_sk = 0, tail_si = 0;   // last chunk / super-chunk of the list and their minima
+        float tail_cs = L.w[63], tail_ss = L.w[63];
+        float best = tep_cost(L, 0.0f, S.d0);
+        u64 bestD = S.d0, bestE = 0;
+        const PbList FL{&B, spill, P.cmin_off};
+        for (int j = 0; j < P.nmax - 1 && nlive > 0; ++j) {
+            // first minimum of the list = arg-min on (sum, slot), read off the super-chunk minima
+            const int nsuper = (nused + 4095) >> 12;
+            float ms = __builtin_inff();
+            int mi = 0x7FFFFFFF;
+            if (lane < nsuper) { const PbEntry t = B.smin[lane]; ms = t.sum; mi = (int)t.pos; }
+            argmin_si(ms, mi, lane);
+            cmp += nlive == 1 ? 1 : 2;
+            // Both levels of the list that this pop touches are loaded NOW, side by side: the 64 slots of the
+            // popped slot's chunk (lane mi & 63 of it is the popped entry itself) and the 64 chunk minima of its
+            // super-chunk.  Everything that changes below (the tombstone, children that land in the same chunk,
+            // the new chunk minimum) is patched into these registers, so one round trip to the spilled part of the
+            // list (global memory) is on the critical path of a TEP instead of three dependent ones.
+            const int ck0 = mi >> 6, sk0 = ck0 >> 6;
+            PbEntry mys, myc;
+            mys.sum = myc.sum = __builtin_inff(); mys.pos = 0; myc.pos = 0x7FFFFFFFu;
+            if (ck0 * 64 + lane < nused) mys = FL.slot(ck0 * 64 + lane);
+            if ((sk0 * 64 + lane) * 64 < nused) myc = FL.cmin(sk0 * 64 + lane);
+            PbEntry e;
+            e.sum = ms;
+            e.pos = (unsigned)__builtin_amdgcn_readlane((int)mys.pos, mi & 63);
+            const int ew = (int)(e.pos >> 24);
+            const int p0 = e.pos & 0xFF, pA = (e.pos >> 8) & 0xFF, pB = (e.pos >> 16) & 0xFF;
+            const int last = ew == 1 ? p0 : (ew == 2 ? pA : pB);
+            const int prev = ew == 2 ? p0 : pA;     // second largest (ew > 1)
+            // children (wave-uniform): extended e U {63}, adjacent = largest index moved down by one
+            PbEntry c1, c2;
+            c1.sum = c2.sum = __builtin_inff(); c1.pos = c2.pos = 0;
+            bool has1 = false, has2 = false;
+            if (last < 63 && ew < P.order) {
+                c1.pos = (e.pos & 0x00FFFFFFu) | (63u << (8 * ew)) | ((unsigned)(ew + 1) << 24);
+                c1.sum = e.sum + L.w[63];
+                has1 = true;
+            }
+            if (ew > 1) {
+                if (last - prev > 1) {
+                    c2.pos = (e.pos & ~(0xFFu << (8 * (ew - 1)))) | ((unsigned)(last - 1) << (8 * (ew - 1)));
+                    const int q0 = c2.pos & 0xFF, q1 = (c2.pos >> 8) & 0xFF, q2 = (c2.pos >> 16) & 0xFF;
+                    float sacc = L.w[q0] + L.w[q1];
+                    if (ew > 2) sacc = sacc + L.w[q2];
+                    c2.sum = sacc;
+                    has2 = true;
+                }
+            } else if (last - 1 > -1) {
+                c2.pos = (unsigned)(last - 1) | (1u << 24);
+                c2.sum = L.w[last - 1];
+                has2 = true;
+            }
+            if (has2 && !has1) { c1 = c2; has1 = true; has2 = false; }      // children in list order: c1 then c2
+            const int s1 = nused, s2 = nused + 1;
+            if (lane == 0) {
+                PbEntry dead;
+                dead.sum = __builtin_inff(); dead.pos = 0;
+                FL.set_slot(mi, dead);
+                if (has1) FL.set_slot(s1, c1);
+                if (has2) FL.set_slot(s2, c2);
+            }
+            nused += (has1 ? 1 : 0) + (has2 ? 1 : 0);
+            nlive += (has1 ? 1 : 0) + (has2 ? 1 : 0) - 1;
+            // ---- chunk level: the popped slot's chunk from the patched registers; the tail chunk incrementally
+            if (lane == (mi & 63)) mys.sum = __builtin_inff();
+            if (has1 && (s1 >> 6) == ck0 && lane == (s1 & 63)) mys = c1;
+            if (has2 && (s2 >> 6) == ck0 && lane == (s2 & 63)) mys = c2;
+            float cs0 = mys.sum;
+            int ci0 = ck0 * 64 + lane;
+            argmin_si(cs0, ci0, lane);
+            if (lane == 0) { PbEntry m; m.sum = cs0; m.pos = (unsigned)ci0; FL.set_cmin(ck0, m); }
+            if (ck0 == tail_ck) { tail_cs = cs0; tail_ci = ci0; }
+            // ---- super-chunk level, same scheme on the chunk minima (patched as the chunk level changes them)
+            if (lane == (ck0 & 63)) { myc.sum = cs0; myc.pos = (unsigned)ci0; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool has = u == 0 ? has1 : has2;
+                const int sl = u == 0 ? s1 : s2;
+                const float csum = u == 0 ? c1.sum : c2.sum;
+                if (!has) continue;
+                const int ck = sl >> 6;
+                if (ck != tail_ck) { tail_ck = ck; tail_cs = __builtin_inff(); tail_ci = 0x7FFFFFFF; }   // a new chunk starts
+                if (ck == ck0) continue;                                   // covered by the reduction above
+                if (csum < tail_cs) { tail_cs = csum; tail_ci = sl; }      // (a tie keeps the older, lower slot)
+                if (lane == 0) { PbEntry m; m.sum = tail_cs; m.pos = (unsigned)tail_ci; FL.set_cmin(ck, m); }
+                if ((ck >> 6) == sk0 && lane == (ck & 63)) { myc.sum = tail_cs; myc.pos = (unsigned)tail_ci; }
+            }
+            float ss0 = myc.sum;
+            int si0 = (int)myc.pos;
+            argmin_si(ss0, si0, lane);
+            if (lane == 0) { PbEntry m; m.sum = ss0; m.pos = (unsigned)si0; B.smin[sk0] = m; }
+            if (sk0 == tail_sk) { tail_ss = ss0; tail_si = si0; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool has = u == 0 ? has1 : has2;
+                const int sl = u == 0 ? s1 : s2;
+                const float csum = u == 0 ? c1.sum : c2.sum;
+                if (!has) continue;
+                const int sk = sl >> 12;
+                if (sk != tail_sk) { tail_sk = sk; tail_ss = __builtin_inff(); tail_si = 0x7FFFFFFF; }
+                if (sk == sk0) continue;
+                if (csum < tail_ss) { tail_ss = csum; tail_si = sl; }
+                if (lane == 0) { PbEntry m; m.sum = tail_ss; m.pos = (unsigned)tail_si; B.smin[sk] = m; }
+            }
+            wave_fence();
+            // promising-probability rule
+            const float rs = e.sum;
+            const float w1 = det_expf(P.c4 * rs) * spl, w2 = 1.0f - w1;
+            const float bt = __builtin_floorf((best - rs) / lrb_mean);
+            const int beta = bt > 0.0f ? (bt < 64.0f ? (int)bt : 64) : 0;
+            float bs = 0.0f;
+            bs = bs + w1 * (float)B.cdfA[beta];
+            bs = bs + w2 * (float)B.cdfH[beta];
+            if ((double)bs < p_t_pro) { stop = 1; ntep = j + 1; break; }
+            u64 D = S.d0 ^ L.P[p0], E = 1ull << p0;
+            if (ew > 1) { D ^= L.P[pA]; E |= 1ull << pA; }
+            if (ew > 2) { D ^= L.P[pB]; E |= 1ull << pB; }
+            const float cost = tep_cost(L, rs, D);
+            ++suc1;
+            if (cost < best) {
+                best = cost; bestD = D; bestE = E; bestidx = j + 1;
+                const float ratio = (1.0f - w1) / w1;
+                float prod = 1.0f;
+#pragma unroll 4
+                for (int p = 0; p < 64; ++p) {
+                    const float qp = B.q[64 + p];
+                    prod = prod * (((D >> p) & 1) ? 2.0f * qp : 2.0f * (1.0f - qp));
+                }
+                const float p_suc = 1.0f / (1.0f + ratio / prod);
+                ++suc2;
+                if ((double)p_suc > p_t_suc) { stop = 2; ntep = j + 1; break; }
+            }
+        }
+        pb_write(L, S, O, f, lane, bestE, bestD, best, bestidx, ntep, cmp, suc1, suc2, stop);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+int pb_ctx_init(ldpc_ctx *ctx)
+{
+    OsdState *st = state(ctx);
+    std::vector<uchar4> tab;
+    tab.reserve(kPbTabSize);
+    for (int p = 63; p >= 0; --p) tab.push_back(make_uchar4((unsigned char)p, 0, 0, 1));
+    for (int p0 = 62; p0 >= 0; --p0)
+        for (int p1 = p0 + 1; p1 < 64; ++p1) tab.push_back(make_uchar4((unsigned char)p0, (unsigned char)p1, 0, 2));
+    for (int p0 = 61; p0 >= 0; --p0)
+        for (int p1 = p0 + 1; p1 < 63; ++p1)
+            for (int p2 = p1 + 1; p2 < 64; ++p2) tab.push_back(make_uchar4((unsigned char)p0, (unsigned char)p1, (unsigned char)p2, 3));
+    if ((int)tab.size() != kPbTabSize) return fail(LDPC_E_CODE, "PB-OSD table has %zu entries", tab.size());
+    LDPC_HIP(hipMalloc((void **)&st->d_pb_tab, sizeof(uchar4) * tab.size()));
+    LDPC_HIP(hipMemcpy(st->d_pb_tab, tab.data(), sizeof(uchar4) * tab.size(), hipMemcpyHostToDevice));
+    return LDPC_OK;
+}
+
+// PB-OSD part of a stream's workspace: control words, the two frame lists, the list replay's spill areas
+static int stream_ws_pb(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int64_t spill_stride, StreamWs **out)
+{
+    OsdState *st = state(ctx);
+    std::lock_guard<std::mutex> lock(st->mu);
+    StreamWs &w = st->ws[s];
+    const bool grow_list = frames > w.pb_cap || !w.d_pb_ctl, grow_spill = spill_stride > w.pb_spill_stride;
+    if ((grow_list || grow_spill) && stream_capturing(s))
+        return fail(LDPC_E_NOMEM, "PB-OSD workspace of this stream must be sized before capturing (run one call on the stream first)");
+    if (grow_list) {
+        (void)hipFree(w.d_pb_list); w.d_pb_list = nullptr; w.pb_cap = 0;
+        if (!w.d_pb_ctl && hipMalloc((void **)&w.d_pb_ctl, sizeof(int) * kPbCtlInts) != hipSuccess)
+            return fail(LDPC_E_NOMEM, "PB-OSD control words could not be allocated");
+        if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * 2 * (size_t)frames) != hipSuccess)
+            return fail(LDPC_E_NOMEM, "PB-OSD frame lists for %lld frames could not be allocated", (long long)frames);
+        w.pb_cap = frames;
+    }
+    if (grow_spill) {
+        (void)hipFree(w.d_pb_spill); w.d_pb_spill = nullptr; w.pb_spill_stride = 0;
+        if (hipMalloc(&w.d_pb_spill, sizeof(PbEntry) * (size_t)spill_stride * kPbSeqBlocks * 4) != hipSuccess)
+            return fail(LDPC_E_NOMEM, "PB-OSD frontier workspace (%lld entries per wave) could not be allocated", (long long)spill_stride);
+        w.pb_spill_stride = spill_stride;
+    }
+    *out = &w;
+    return LDPC_OK;
+}
+
+int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+              const unsigned char *d_perm, const u64 *d_parity, const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric,
+              int32_t *d_best, int32_t *d_ntep, hipStream_t s)
+{
+    OsdState *st = state(ctx);
+    const int64_t nmax = st->ntep[p->order];
+    // list replay: the list is append-only, at most 1 + 2 (N_max - 1) slots; spilled slots first, spilled chunk minima after
+    const int64_t slots = 2 * nmax + 2;
+    if (slots > (int64_t)kPbSuper * 4096) return fail(LDPC_E_UNSUPPORTED, "ldpc_osd_decode: PB-OSD list of %lld slots exceeds the kernel's limit", (long long)slots);
+    const int64_t spill_slots = slots > kPbLdsSlots ? slots - kPbLdsSlots : 0;
+    const int64_t stride = spill_slots + (slots / 64 + 2) + 2;
+    StreamWs *w;
+    int rc = stream_ws_pb(ctx, s, F, stride, &w);
+    if (rc) return rc;
+    PbParams pp;
+    pp.order = p->order; pp.nmax = (int)nmax; pp.cmin_off = spill_slots;
+    pp.c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)p->snr_db / 10.0)));    // -4 * noise_variance, pb_testing.py:50-52
+    const int mode = (p->reserved & 4) ? 2 : ((p->reserved & 2) ? 1 : 0);
+    PbOut O{reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep, reinterpret_cast<int *>(p->d_aux)};
+    int *listA = w->d_pb_list, *listB = w->d_pb_list + w->pb_cap;
+    LDPC_HIP(hipMemsetAsync(w->d_pb_ctl, 0, sizeof(int) * kPbCtlInts, s));
+    const int64_t want = (F + 3) / 4;
+    const unsigned g1 = (unsigned)(want < 1 ? 1 : (want < 8192 ? want : 8192));
+    hipLaunchKernelGGL(pb_singles_kernel, dim3(g1), dim3(256), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
+                       st->d_cdf_half, st->d_coef, w->d_pb_ctl, listA, listB, O);
+    const unsigned g2 = (unsigned)(F < 1024 ? F : 1024);
+    hipLaunchKernelGGL((pb_block_kernel<256, 2048>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half,
+                       st->d_coef, st->d_pb_tab, w->d_pb_ctl, listA, listB, O);
+    const unsigned g3 = (unsigned)(want < kPbSeqBlocks ? (want < 1 ? 1 : want) : kPbSeqBlocks);
+    hipLaunchKernelGGL(pb_seq_kernel, dim3(g3), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half, st->d_coef,
+                       reinterpret_cast<PbEntry *>(w->d_pb_spill), (long long)w->pb_spill_stride, w->d_pb_ctl, listB, O);
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
+}
+
+}  // namespace ldpc

@@ -1,0 +1,47 @@
+// Host-side OSD state of a context: TEP tables and the per-stream workspaces (ldpc_osd.hip, ldpc_osd_pb.hip).
+#pragma once
+
+#include "ldpc_wave.h"
+
+namespace ldpc {
+
+// Everything a decode call writes besides the caller's buffers lives in a workspace that belongs to the
+// STREAM the call is issued on (created on that stream's first call, grown on demand, found under a mutex):
+// calls on different streams of one context never share scratch, so they may overlap freely.
+struct StreamWs {
+    unsigned char *d_perm = nullptr;  // ldpc_osd_decode: front-end results [cap][128]
+    u64 *d_parity = nullptr;          //                                    [cap][64]
+    int64_t cap = 0;
+    int *d_pb_ctl = nullptr;          // PB-OSD: frame tickets and list lengths (kPbCtlInts ints, zeroed per call)
+    int *d_pb_list = nullptr;         // PB-OSD: [2][pb_cap] frames handed on to the block kernel / the sequential kernel
+    int64_t pb_cap = 0;
+    void *d_pb_spill = nullptr;       // PB-OSD sequential kernel: frontier overflow [waves][stride]
+    int64_t pb_spill_stride = 0;
+};
+constexpr int kPbCtlInts = 8;         // {ticket 1, list A length, ticket 2, list B length, ticket 3, -, -, -}
+constexpr int kPbSeqBlocks = 64;      // grid of the sequential PB kernel (each of its 4 x 64 waves owns a spill area)
+
+struct OsdState {
+    int64_t ntep[4] = {0, 0, 0, 0};
+    uchar4 *d_tep_fs = nullptr;       // FS visit order, weight classes 1..3 back to back
+    int *d_base2 = nullptr;           // order-2 ranks: number of index pairs with a larger sum
+    double *d_cdf_half = nullptr;     // PB-OSD: P[Bin(64, 1/2) <= b], b = 0..64
+    double *d_coef = nullptr;         // PB-OSD: (64-i)/(i+1)
+    uchar4 *d_pb_tab = nullptr;       // PB-OSD: TEPs by weight class, each class by descending smallest position (pb_tables)
+    int fs_off[4] = {0, 0, 0, 0}, fs_cnt[4] = {0, 0, 0, 0};
+    std::mutex mu;                    // guards `ws` and `reserve_frames`
+    std::unordered_map<hipStream_t, StreamWs> ws;
+    int64_t reserve_frames = 0;       // ldpc_osd_reserve: smallest capacity any workspace is created with
+};
+
+static inline OsdState *state(ldpc_ctx *ctx) { return reinterpret_cast<OsdState *>(ctx->osd_state); }
+
+// ldpc_osd_pb.hip
+int pb_ctx_init(ldpc_ctx *ctx);
+int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+              const unsigned char *d_perm, const u64 *d_parity, const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric,
+              int32_t *d_best, int32_t *d_ntep, hipStream_t s);
+// ldpc_osd.hip
+bool stream_capturing(hipStream_t s);
+
+}  // namespace ldpc

@@ -46,16 +46,27 @@ __global__ __launch_bounds__(256) void eval_counts_kernel(const unsigned long lo
 }
 
 // ---------------------------------------------------------------------------------------
-// Ordered compaction: blocks of kChunk flags.  Pass 1 writes one count per block; pass 2
-// lets every block add up the counts of the blocks before it (<= a few hundred values),
-// redo its local scan and scatter ascending frame numbers.  The last block writes the total.
+// Ordered compaction in ONE launch and with NO scratch memory (so calls on different streams of one
+// context cannot disturb each other).  The flags are cut into at most kMaxSeg contiguous segments, one
+// per block.  A block first counts the set flags BEFORE its segment itself -- 16 flags per load, the flag
+// array is L2-resident (1 B per frame: the last of 64 blocks re-reads 126 KiB at B = 131 072) -- and then
+// scans its own segment 2048 flags at a time, scattering ascending frame numbers.  The redundant prefix
+// reads grow with B / 2 per block, i.e. stay ~1 % of the NMS time of the same batch at any B.
+// The block that owns the last segment writes the total.
 // ---------------------------------------------------------------------------------------
-constexpr int kChunk = 2048;  // flags per block: 256 threads x 8
+constexpr int kChunk = 2048;   // flags per block and step: 256 threads x 8
+constexpr int kMaxSeg = 256;   // segments (= blocks) per launch
 
-__device__ __forceinline__ unsigned flags8(const unsigned char *flag, long long base, long long B)
+__device__ __forceinline__ int nonzero_bytes(unsigned long long v)
+{
+    const unsigned long long k7 = 0x7F7F7F7F7F7F7F7Full;
+    return __popcll((((v & k7) + k7) | v) & ~k7);
+}
+
+__device__ __forceinline__ unsigned flags8(const unsigned char *flag, long long base, long long B, bool aligned)
 {
     unsigned bits = 0;
-    if (base + 8 <= B) {
+    if (aligned && base + 8 <= B) {
         unsigned long long v = *reinterpret_cast<const unsigned long long *>(flag + base);
 #pragma unroll
         for (int i = 0; i < 8; ++i) bits |= (unsigned)(((v >> (8 * i)) & 0xFF) != 0) << i;
@@ -65,82 +76,88 @@ __device__ __forceinline__ unsigned flags8(const unsigned char *flag, long long 
     return bits;
 }
 
-// EVAL: the get_eval counters of the same frames ride along (ldpc_pipeline_run: one launch instead of
-// eval_counts_kernel + compact_count_kernel; the flags are the syndrome flags either way)
-template <bool EVAL>
-__global__ __launch_bounds__(256) void compact_count_kernel(const unsigned char *__restrict__ flag, long long B,
-                                                            int *__restrict__ blocksum,
-                                                            const unsigned long long *__restrict__ hard,
-                                                            const unsigned long long *__restrict__ label, int words,
-                                                            unsigned long long *__restrict__ counts)
+__device__ __forceinline__ int block_sum_256(int v, int *wsum /*[4] shared*/)
 {
-    __shared__ int part[4];
-    __shared__ unsigned long long epart[4][4];
-    const long long base = (long long)blockIdx.x * kChunk + threadIdx.x * 8;
-    const unsigned bits = base < B ? flags8(flag, base, B) : 0;
-    int c = __popc(bits);
-    unsigned long long ferr = 0, berr = 0, und = 0, cnt = 0;
-    if constexpr (EVAL) {
-        for (int i = 0; i < 8 && base + i < B; ++i) {
-            const long long f = base + i;
-            int e = 0;
-            for (int w = 0; w < words; ++w) e += __popcll(hard[f * words + w] ^ label[f * words + w]);
-            cnt += 1; berr += e; ferr += e != 0; und += (!((bits >> i) & 1) && e != 0);
-        }
-        cnt = wave_sum(cnt); ferr = wave_sum(ferr); berr = wave_sum(berr); und = wave_sum(und);
-    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        part[wave] = c;
-        if constexpr (EVAL) { epart[wave][0] = cnt; epart[wave][1] = ferr; epart[wave][2] = berr; epart[wave][3] = und; }
-    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();                         // wsum may still be read from an earlier use
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) blocksum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    return wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// EVAL: the get_eval counters of the same frames ride along (ldpc_pipeline_run: the flags are the
+// syndrome flags either way), so the pipeline needs neither eval_counts_kernel nor a second pass
+template <bool EVAL>
+__global__ __launch_bounds__(256) void compact_kernel(const unsigned char *__restrict__ flag, long long B, long long seg,
+                                                      int *__restrict__ index, int *__restrict__ count,
+                                                      const unsigned long long *__restrict__ hard,
+                                                      const unsigned long long *__restrict__ label, int words,
+                                                      unsigned long long *__restrict__ counts)
+{
+    __shared__ int wsum[4];
+    __shared__ unsigned long long epart[4][4];
+    const long long lo = (long long)blockIdx.x * seg;
+    const long long hi = lo + seg < B ? lo + seg : B;
+    const bool al16 = (reinterpret_cast<unsigned long long>(flag) & 15) == 0;
+    // ---- set flags before this segment (lo is a multiple of kChunk)
+    int acc = 0;
+    if (al16) {
+        for (long long i = (long long)threadIdx.x * 16; i < lo; i += 256 * 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(flag + i);
+            acc += nonzero_bytes(((unsigned long long)v.y << 32) | v.x) + nonzero_bytes(((unsigned long long)v.w << 32) | v.z);
+        }
+    } else {
+        for (long long i = threadIdx.x; i < lo; i += 256) acc += flag[i] != 0;
+    }
+    int base = block_sum_256(acc, wsum);
+    // ---- own segment
+    unsigned long long ferr = 0, berr = 0, und = 0, cnt = 0;
+    const int lane = threadIdx.x & 63;
+    for (long long c0 = lo; c0 < hi; c0 += kChunk) {
+        const long long fb = c0 + threadIdx.x * 8;
+        const unsigned bits = fb < hi ? flags8(flag, fb, hi, al16) : 0;
+        const int mine = __popc(bits);
+        if constexpr (EVAL) {
+            for (int i = 0; i < 8 && fb + i < hi; ++i) {
+                const long long f = fb + i;
+                int e = 0;
+                for (int w = 0; w < words; ++w) e += __popcll(hard[f * words + w] ^ label[f * words + w]);
+                cnt += 1; berr += e; ferr += e != 0; und += (!((bits >> i) & 1) && e != 0);
+            }
+        }
+        int incl = mine;   // exclusive scan over the 256 threads: in-wave inclusive scan, then wave offsets
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        __syncthreads();
+        if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        int pos = base + woff + incl - mine;
+        for (int i = 0; i < 8; ++i)
+            if ((bits >> i) & 1) index[pos++] = (int)(fb + i);
+        base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+    if (hi == B && threadIdx.x == 0) *count = base;
     if constexpr (EVAL) {   // counts[] = {frames, frame_err, bit_err, undetected, synd_fail}
+        cnt = wave_sum(cnt); ferr = wave_sum(ferr); berr = wave_sum(berr); und = wave_sum(und);
+        if (lane == 0) { const int w = threadIdx.x >> 6; epart[w][0] = cnt; epart[w][1] = ferr; epart[w][2] = berr; epart[w][3] = und; }
+        const int before = block_sum_256(acc, wsum);   // (also the barrier that publishes epart)
         if (threadIdx.x < 4) atomicAdd(&counts[threadIdx.x], epart[0][threadIdx.x] + epart[1][threadIdx.x] + epart[2][threadIdx.x] + epart[3][threadIdx.x]);
-        if (threadIdx.x == 4) atomicAdd(&counts[4], (unsigned long long)(part[0] + part[1] + part[2] + part[3]));
+        if (threadIdx.x == 4) atomicAdd(&counts[4], (unsigned long long)(base - before));
     }
 }
 
-__global__ __launch_bounds__(256) void compact_scatter_kernel(const unsigned char *__restrict__ flag, long long B,
-                                                              const int *__restrict__ blocksum,
-                                                              int *__restrict__ index, int *__restrict__ count)
+static void compact_geometry(int64_t B, unsigned *blocks, long long *seg)
 {
-    __shared__ int wsum[4];
-    __shared__ int s_base;
-    // offset of this block = sum of the counts of all earlier blocks
-    int acc = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) acc += blocksum[b];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-    const int block_base = s_base;
-    __syncthreads();
-
-    const long long base = (long long)blockIdx.x * kChunk + threadIdx.x * 8;
-    const unsigned bits = base < B ? flags8(flag, base, B) : 0;
-    const int mine = __popc(bits);
-    // exclusive scan over the 256 threads: in-wave inclusive scan, then wave offsets
-    int incl = mine;
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
-    int pos = block_base + woff + incl - mine;
-    for (int i = 0; i < 8; ++i)
-        if ((bits >> i) & 1) index[pos++] = (int)(base + i);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *count = block_base + woff + incl;
+    const int64_t chunks = (B + kChunk - 1) / kChunk;
+    const int64_t per = (chunks + kMaxSeg - 1) / kMaxSeg;   // chunks per segment
+    *seg = (long long)per * kChunk;
+    *blocks = (unsigned)((B + *seg - 1) / *seg);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -206,15 +223,11 @@ int ldpc_compact(ldpc_ctx *ctx, const uint8_t *d_flag, int64_t B, int32_t *d_ind
         return fail(LDPC_E_ARG, "ldpc_compact: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) { LDPC_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return LDPC_OK; }
-    const int64_t blocks = (B + kChunk - 1) / kChunk;
-    if (blocks > ctx->blocksum_cap)
-        return fail(LDPC_E_UNSUPPORTED, "ldpc_compact: B=%lld exceeds the context's scratch (%lld frames)", (long long)B,
-                    (long long)ctx->blocksum_cap * kChunk);
-    hipLaunchKernelGGL(compact_count_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, d_flag, (long long)B,
-                       ctx->d_blocksum, (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, 0,
+    unsigned blocks; long long seg;
+    compact_geometry(B, &blocks, &seg);
+    hipLaunchKernelGGL(compact_kernel<false>, dim3(blocks), dim3(256), 0, st, d_flag, (long long)B, seg, d_index, d_count,
+                       (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, 0,
                        (unsigned long long *)nullptr);
-    hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_flag, (long long)B,
-                       ctx->d_blocksum, d_index, d_count);
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;
 }
@@ -223,22 +236,18 @@ int ldpc_compact(ldpc_ctx *ctx, const uint8_t *d_flag, int64_t B, int32_t *d_ind
 
 namespace ldpc {
 
-// ldpc_eval_counts + ldpc_compact on the same flags with one launch fewer (ldpc_pipeline_run)
+// ldpc_eval_counts + ldpc_compact on the same flags in one launch (ldpc_pipeline_run)
 int eval_and_compact(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_label, const uint8_t *d_fail, int64_t B,
                      int64_t *d_counts, int32_t *d_index, int32_t *d_count, hipStream_t st)
 {
     if (!ctx || !d_hard || !d_label || !d_fail || !d_counts || !d_index || !d_count || B <= 0 || B > 0x7FFFFFFFLL)
         return fail(LDPC_E_ARG, "eval_and_compact: bad arguments");
-    const int64_t blocks = (B + kChunk - 1) / kChunk;
-    if (blocks > ctx->blocksum_cap)
-        return fail(LDPC_E_UNSUPPORTED, "ldpc_compact: B=%lld exceeds the context's scratch (%lld frames)", (long long)B,
-                    (long long)ctx->blocksum_cap * kChunk);
-    hipLaunchKernelGGL(compact_count_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, d_fail, (long long)B,
-                       ctx->d_blocksum, reinterpret_cast<const unsigned long long *>(d_hard),
+    unsigned blocks; long long seg;
+    compact_geometry(B, &blocks, &seg);
+    hipLaunchKernelGGL(compact_kernel<true>, dim3(blocks), dim3(256), 0, st, d_fail, (long long)B, seg, d_index, d_count,
+                       reinterpret_cast<const unsigned long long *>(d_hard),
                        reinterpret_cast<const unsigned long long *>(d_label), (ctx->code.n + 63) / 64,
                        reinterpret_cast<unsigned long long *>(d_counts));
-    hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_fail, (long long)B,
-                       ctx->d_blocksum, d_index, d_count);
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;
 }

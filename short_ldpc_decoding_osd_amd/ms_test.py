@@ -17,10 +17,7 @@ import torch
 
 from . import globalmap as GL
 from .runtime import default_decoder
-
-
-def _softplus32(x):
-    return np.float32(np.log1p(np.exp(np.float64(x))))
+from .weights import softplus32 as _softplus32
 
 
 class Decoder_Layer:

@@ -161,11 +161,14 @@ class Decoder:
         return perm, parity, ns
 
     def osd_params(self, order, algo=_lib.OSD_CONVENTIONAL, snr_db=0.0, fs_beta=0.1, fs_tau_e=6.5, fs_tau_psc=30.0,
-                   fs_reference_quirk=1, aux=None, table_scan=False):
+                   fs_reference_quirk=1, aux=None, table_scan=False, pb_path=None):
         """aux: optional int32 tensor [F,4] receiving the PB-OSD per-frame statistics;
-        table_scan: use the table-driven conventional kernel also for order 2 (cross-check path)."""
+        table_scan: use the table-driven conventional kernel also for order 2 (cross-check path);
+        pb_path: None = staged PB-OSD kernels, "block" = every frame through the sorted-chunk workgroup
+        kernel, "replay" = every frame through the literal list replay (cross-check paths)."""
+        flags = (1 if table_scan else 0) | {None: 0, "block": 2, "replay": 4}[pb_path]
         return _lib.OsdParams(int(order), int(algo), float(snr_db), float(fs_beta), float(fs_tau_e),
-                              float(fs_tau_psc), int(fs_reference_quirk), 1 if table_scan else 0,
+                              float(fs_tau_psc), int(fs_reference_quirk), flags,
                               aux.data_ptr() if aux is not None else None)
 
     def osd_decode(self, y, order, algo=_lib.OSD_CONVENTIONAL, index=None, count=None, F=None, params=None, out=None):

@@ -12,6 +12,19 @@ import re
 
 import numpy as np
 
+
+
+def softplus32(x):
+    """softplus of a stored weight -> effective factor (ms_test.py:207-208 applies tf.nn.softplus to a float32
+    variable).  ONE convention for the whole package: log1p(exp(x)) evaluated in float32.  (TensorFlow is not
+    available to pin the last bit -- parity unpinned; for the shipped weight -0.048 the float32 and the float64
+    evaluation round to the same float32, 0.66943514.)"""
+    x = np.float32(x)
+    return np.float32(np.log1p(np.exp(x)))
+
+
+STORED_NMS1_WEIGHT = -0.048      # Decoder_Layer's initial value, the only weight the reference ships (ms_test.py:73,83)
+
 _HEADER = re.compile(r"For all layers at the\s*(\d+)-th step:")
 _ENTRY = re.compile(r"([A-Za-z_][\w /.\-]*?(?::\d+)?)\s*\[\s*([-+0-9.eE]+(?:\s+[-+0-9.eE]+)*)\s*\]")
 

@@ -18,7 +18,7 @@ def test_header_and_binding_agree():
     L = _lib.load()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.ldpc_abi_version() == 1
+    assert L.ldpc_abi_version() == 2
 
 
 @pytest.mark.parametrize("name,alist", [

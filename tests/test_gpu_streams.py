@@ -1,0 +1,82 @@
+"""-m gpu: decode calls on DIFFERENT streams of ONE context must not disturb each other (include/ldpc_osd.h,
+ldpc_ctx_create): the compaction uses no scratch, everything else a per-stream workspace.  Three pipelines with
+different batches run concurrently on three streams; every output must equal the single-stream run."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle
+from tests.gpu_util import pack_np, to_dev
+
+pytestmark = pytest.mark.gpu
+ALPHA0 = 0.669435
+
+
+@pytest.fixture(scope="module")
+def dec():
+    from short_ldpc_decoding_osd_amd import Code
+    from short_ldpc_decoding_osd_amd.runtime import Decoder
+    return Decoder(Code())
+
+
+def _snapshot(pipe):
+    n = int(pipe.count.cpu()[0])
+    return dict(count=n, index=pipe.index[:n].cpu().numpy().copy(), cw=pipe.cw[:n].cpu().numpy().copy(),
+                metric=pipe.metric[:n].cpu().numpy().copy(), ntep=pipe.ntep[:n].cpu().numpy().copy(),
+                hard=pipe.hard.cpu().numpy().copy(), counters=pipe.counters().cpu().numpy().copy())
+
+
+@pytest.mark.parametrize("algo,order,B", [("conv", 2, 40000), ("pb", 3, 6000), ("fs", 2, 20000)])
+def test_three_streams_one_context(dec, algo, order, B):
+    from short_ldpc_decoding_osd_amd import _lib
+    from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline
+    algo_id = {"conv": _lib.OSD_CONVENTIONAL, "pb": _lib.OSD_PB, "fs": _lib.OSD_FS}[algo]
+    pipes = []
+    for lane in range(3):
+        rng = np.random.default_rng(100 + lane)
+        y, cw = np_oracle.make_frames(dec.code.G, 2.5, B - 1000 * lane, rng)    # different sizes: different block counts
+        # keep_front=False: the OSD goes through ldpc_osd_decode and the stream's own workspace
+        p = BatchPipeline(dec, y.shape[0], 10, ALPHA0, osd_order=order, osd_algo=algo_id, snr_db=2.5, keep_front=(lane != 1))
+        pipes.append(p.bind(to_dev(y, dec), to_dev(pack_np(cw).view(np.int64), dec)))
+    want = []
+    for p in pipes:                      # reference: one after the other on the current stream
+        p.reset_counters()
+        p.run()
+        torch.cuda.synchronize()
+        want.append(_snapshot(p))
+    streams = [torch.cuda.Stream() for _ in pipes]
+    rounds = 4
+    for p in pipes:
+        p.reset_counters()
+    torch.cuda.synchronize()
+    for _ in range(rounds):              # all three in flight at once, several times
+        for st, p in zip(streams, pipes):
+            with torch.cuda.stream(st):
+                p.run()
+    torch.cuda.synchronize()
+    for p, w in zip(pipes, want):
+        got = _snapshot(p)
+        assert got["count"] == w["count"]
+        for k in ("index", "cw", "metric", "ntep", "hard"):
+            assert np.array_equal(got[k], w[k]), k
+        assert np.array_equal(got["counters"], rounds * w["counters"])
+
+
+def test_compact_unaligned_and_ragged(dec):
+    """The one-launch compaction: segment boundaries, a flag pointer that is not 16-byte aligned, empty and full inputs."""
+    rng = np.random.default_rng(5)
+    for B in (1, 7, 2047, 2048, 2049, 65536 + 13, 600001):
+        base = torch.from_numpy((rng.random(B + 3) < 0.3).astype(np.uint8) * rng.integers(1, 255, B + 3).astype(np.uint8)).to(dec.device)
+        for off in (0, 3):
+            flag = base[off:off + B]
+            index, count = dec.compact(flag)
+            torch.cuda.synchronize()
+            ref = np.flatnonzero(flag.cpu().numpy())
+            n = int(count.cpu()[0])
+            assert n == ref.size and np.array_equal(index[:n].cpu().numpy(), ref), (B, off)
+    for val in (0, 1):
+        flag = torch.full((5000,), val, dtype=torch.uint8, device=dec.device)
+        index, count = dec.compact(flag)
+        assert int(count.cpu()[0]) == 5000 * val
+        if val:
+            assert np.array_equal(index.cpu().numpy(), np.arange(5000))

@@ -180,3 +180,32 @@ def test_pb_osd_c_vs_numpy(np_code):
                  and o["comparisons"] == res["comparisons"][j] and o["best_index"] == res["best_index"][j]
                  and np.array_equal(cwo, res["codeword"][j]) and o["fail"] == (not res["correct"][j]))
     assert same >= len(idx) - 1
+
+
+def test_testing_data_generating_matches_reference(np_code, golden_dir):
+    """a10: frames and labels of the reference's own generator (Testing_data_gen_128/data_generating.py:13-51, imported
+    by oracle/gen_golden.py, global NumPy RNG seeded) against the package mirror on the legacy RNG and against
+    np_oracle.make_frames fed with the same draws."""
+    from short_ldpc_decoding_osd_amd import Code, globalmap as GL
+    from short_ldpc_decoding_osd_amd.data_generating import testing_data_generating
+
+    class LegacyDraws:          # the global RandomState behind a Generator-like face
+        normal = staticmethod(np.random.normal)
+
+        @staticmethod
+        def integers(lo, hi, size):
+            return np.random.randint(lo, hi, size=size)
+
+    g = np.load(os.path.join(golden_dir, "testgen_ccsds.npz"))
+    code = Code()
+    GL.set_map('Rayleigh_fading', False)
+    GL.set_map('ALL_ZEROS_CODEWORD_TESTING', False)
+    for i, (seed, snr, frames) in enumerate(g["cases"]):
+        want_y, want_lab = g[f"data{i}"], g[f"labels{i}"].astype(np.int64)
+        np.random.seed(int(seed))
+        y, lab = testing_data_generating(code, float(snr), int(frames))
+        assert y.dtype == np.float64 and np.array_equal(y, want_y) and np.array_equal(lab, want_lab)
+        np.random.seed(int(seed))
+        y32, cw = np_oracle.make_frames(np_code.G, float(snr), int(frames), LegacyDraws)
+        assert np.array_equal(y32, want_y.astype(np.float32)) and np.array_equal(cw, want_lab)
+        assert not (np_code.H.dot(want_lab.T) % 2).any()          # the reference's labels are codewords of H

@@ -1,4 +1,6 @@
-"""CPU, world_size 2 over gloo: the N > 1 path (frame sharding + counter all-reduce)."""
+"""CPU, world_size 2 over gloo: the N > 1 path (frame sharding + counter all-reduce).  There is no CPU decode path
+in the product, so the ranks decode their shard of REAL frames with the C oracle (the checker) and the reduced
+counters are compared with a single-process decode of the whole batch."""
 import os
 import socket
 import sys
@@ -58,6 +60,71 @@ def test_world2_counters(total):
     f = combine_fer(c0)
     assert f["fer_product"] == pytest.approx(f["synd_fail_rate"] * f["fer_osd_given_fail"])
     assert f["mean_teps"] == 2081
+
+
+def _oracle_counters(y, cw):
+    """{frames, frame_err, bit_err, undetected, synd_fail, osd_frames, osd_wrong, teps} of NMS-10 + OSD-1 by the C oracle."""
+    import numpy as np
+    from oracle import c_oracle, np_oracle
+    code = np_oracle.Code(os.path.join(ROOT, "short_ldpc_decoding_osd_amd", "data", "CCSDS_ldpc_n128_k64.alist"))
+    soft = c_oracle.nms(code.H, y, 10, 0.669435)
+    hard, fail, cnt = c_oracle.evaluate(code.H, soft, cw)
+    idx = np.flatnonzero(fail)
+    wrong = int((~c_oracle.conv_osd(code.G, y[idx], cw[idx], 1)["correct"]).sum()) if idx.size else 0
+    return [y.shape[0], cnt["frame_err"], cnt["bit_err"], cnt["undetected"], cnt["synd_fail"], idx.size, wrong, 65 * idx.size]
+
+
+def _decode_worker(rank, world, port, total, out):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    from oracle import np_oracle
+    from short_ldpc_decoding_osd_amd.sharding import allreduce_counters, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    code = np_oracle.Code(os.path.join(ROOT, "short_ldpc_decoding_osd_amd", "data", "CCSDS_ldpc_n128_k64.alist"))
+    y, cw = np_oracle.make_frames(code.G, 2.5, total, np.random.default_rng(99))     # the same global batch on every rank
+    lo, hi = shard_range(total, rank, world)
+    c = allreduce_counters(torch.tensor(_oracle_counters(y[lo:hi], cw[lo:hi]), dtype=torch.int64))
+    out.put((rank, c.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_decodes_real_frames():
+    """Each rank decodes its contiguous shard; the all-reduced counters equal the single-process decode."""
+    import numpy as np
+    from oracle import np_oracle
+    total = 3001
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_decode_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    code = np_oracle.Code(os.path.join(ROOT, "short_ldpc_decoding_osd_amd", "data", "CCSDS_ldpc_n128_k64.alist"))
+    y, cw = np_oracle.make_frames(code.G, 2.5, total, np.random.default_rng(99))
+    want = [int(v) for v in _oracle_counters(y, cw)]
+    assert got[0][1] == want and got[1][1] == want
+    assert want[4] > 500 and want[6] > 0          # the batch really has NMS failures and OSD-1 errors
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` without a launcher spawns its own ranks -- or fails loudly, never a 1-GPU number."""
+    import subprocess
+    have = torch.cuda.device_count()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 2), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
+    assert p.returncode != 0 and "GPU(s) visible" in p.stderr and not p.stdout.strip()
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and not p.stdout.strip()
 
 
 def test_shard_range_edges():
