@@ -485,8 +485,12 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
             const bool use_hist = cnt > CAP;
             float scale = 0.0f;
             if (use_hist) {
-                if (!(mn < mx)) { if (tid == 0) B.degenerate = 1; __syncthreads(); break; }   // > CAP equal sums
                 scale = (float)kPbBins / (mx - mn);
+                if (!(mn < mx) || !(scale < 3.0e38f)) {   // > CAP equal (or denormally close) sums
+                    if (tid == 0) B.degenerate = 1;
+                    __syncthreads();
+                    break;
+                }
                 for (int b = tid; b < kPbBins; b += NT) B.hist[b] = 0;
                 __syncthreads();
                 for (int i = tid; i < total; i += NT) {
@@ -539,6 +543,11 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
             }
             __syncthreads();
             const int n = B.nkeys;
+            if (n == 0) {   // (cannot happen: the bin of the smallest sum is never empty) -- zoom rather than trust it
+                if (tid == 0) B.hi_cur = mn + (mx - mn) * (1.0f / (float)kPbBins);
+                __syncthreads();
+                continue;
+            }
             int npow = 2;
             while (npow < n) npow <<= 1;
             for (int i = n + tid; i < npow; i += NT) B.keys[i] = ~0ull;
