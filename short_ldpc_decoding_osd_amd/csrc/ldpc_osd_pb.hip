@@ -29,6 +29,8 @@
 //                      appended to list B.
 //   pb_seq_kernel      the literal list replay (round-1 kernel) for list B.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "ldpc_internal.h"
 #include "ldpc_wave.h"
@@ -100,6 +102,14 @@ __device__ __forceinline__ void argmin_si(float &s, int &idx, int lane)
 }
 
 
+// (64 - i) / (i + 1): the ratio of consecutive binomial coefficients C(64, i+1) / C(64, i), correctly rounded
+// float64 -- the same values the host computes for the oracle's recurrence
+struct PbCoef {
+    double v[64];
+    constexpr PbCoef() : v() { for (int i = 0; i < 64; ++i) v[i] = (double)(64 - i) / (double)(i + 1); }
+};
+__constant__ PbCoef kPbCoef;
+
 // per-frame PB quantities (wave-uniform), float conventions of the oracle
 struct PbFrame {
     float spl, lrb_mean;       // prod (1 - q_p) over the MRB (com_mrb_prob :35-41), mean |y'| over the LRB (:401)
@@ -134,7 +144,7 @@ __device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, 
         if (lane == 0) cdfA[0] = acc;
 #pragma unroll 2
         for (int i = 0; i < 64; ++i) {
-            t = t * coef[i] * ratio;
+            t = t * kPbCoef.v[i] * ratio;
             acc = acc + t;
             if (lane == 0) cdfA[i + 1] = acc;
         }
@@ -142,7 +152,7 @@ __device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, 
         for (int s = 0; s < 6; ++s) t = t * t;
         const double ratio2 = (double)pt / qq;
         acc = t;
-        for (int i = 0; i < order; ++i) { t = t * coef[i] * ratio2; acc = acc + t; }
+        for (int i = 0; i < order; ++i) { t = t * kPbCoef.v[i] * ratio2; acc = acc + t; }
         niu = acc;
     }
     PbFrame F;
@@ -370,16 +380,24 @@ struct __attribute__((aligned(16))) PbBlockLds {
     u64 keys[CAP];          // (sum bits << 32) | table id
     float cost[CAP];
     int hist[kPbBins];
+    int binoff[kPbBins + 1];
     float red_f[2][NT / 64];
     int red_i[2][NT / 64];
     PbFrame fr;
     // uniform search state
     float lo, hi_cur, best;
-    int theta_i, j, nlive, cmp, suc1, suc2, bestidx;
+    int j, nlive, cmp, suc1, suc2, bestidx;
     u64 bestD, bestE, d0;
     // per-chunk scratch
     int nkeys, bstar, degenerate, gstop, reason, ones, nev, nnb, lnb, ticket;
+    unsigned long long prof[16], prof_last;   // diagnostic build only (LDPC_PB_PROFILE)
 };
+
+// In-kernel stamps of the diagnostic instantiation (PROF = true, launched only when LDPC_PB_PROFILE is set): thread 0
+// adds the shader cycles since the previous stamp to slot k.  The product instantiation contains none of this.
+enum { kProfSetup = 0, kProfPassA, kProfHist, kProfGather, kProfSort, kProfTie, kProfEval1, kProfEval2, kProfCombine, kProfFill,
+       kProfScatter, kProfFinish, kProfFrames, kProfChunks };
+#define PB_STAMP(k) do { if constexpr (PROF) { if (tid == 0) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); B.prof[k] += now__ - B.prof_last; B.prof_last = now__; } } } while (0)
 
 // candidate prefix lengths of the three weight classes for the sum bound `hi` (all TEPs with sum <= hi have
 // their smallest position in the prefix; the slack terms cover the roundings of the float32 sums)
@@ -404,20 +422,229 @@ __device__ __forceinline__ void pb_cand(const uchar4 *__restrict__ tab, const fl
     else { id = kPbTriples0 + (i - n1 - n2); const uchar4 t = tab[id]; sum = (w[t.x] + w[t.y]) + w[t.z]; }
 }
 
+// block reductions of (count, min, max); every thread gets the results
 template <int NT, int CAP>
+__device__ __forceinline__ void pb_reduce3(PbBlockLds<NT, CAP> &B, int &cnt, float &mn, float &mx, int lane, int wave)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_xor(cnt, off, 64);
+        mn = __builtin_fminf(mn, __shfl_xor(mn, off, 64));
+        mx = __builtin_fmaxf(mx, __shfl_xor(mx, off, 64));
+    }
+    if (lane == 0) { B.red_i[0][wave] = cnt; B.red_f[0][wave] = mn; B.red_f[1][wave] = mx; }
+    __syncthreads();
+    cnt = 0; mn = __builtin_inff(); mx = -1.0f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { cnt += B.red_i[0][w]; mn = __builtin_fminf(mn, B.red_f[0][w]); mx = __builtin_fmaxf(mx, B.red_f[1][w]); }
+    __syncthreads();
+}
+
+// Largest bin b in (bprev, kPbBins) such that hist[bprev+1 .. b] holds <= CAP entries (-1 if even the first bin
+// does not fit), and that count; every thread gets both.
+template <int NT, int CAP>
+__device__ __forceinline__ int pb_pick_bins(PbBlockLds<NT, CAP> &B, int bprev, int &count, int tid, int lane, int wave)
+{
+    constexpr int PERB = kPbBins / NT, W = NT / 64;
+    int local = 0;
+#pragma unroll
+    for (int q = 0; q < PERB; ++q) { const int b = tid * PERB + q; local += b > bprev ? B.hist[b] : 0; }
+    const int incl = wave_incl_add(local, lane);
+    if (lane == 63) B.red_i[0][wave] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w = 0; w < wave; ++w) run += B.red_i[0][w];
+    int mybest = -1, mycount = 0;
+#pragma unroll
+    for (int q = 0; q < PERB; ++q) {
+        const int b = tid * PERB + q;
+        run += b > bprev ? B.hist[b] : 0;
+        if (b > bprev && run <= CAP) { mybest = b; mycount = run; }
+    }
+    // arg-max on the bin index (counts are non-decreasing in the bin, so the count of the largest bin is the largest)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int t = __shfl_xor(mybest, off, 64), c = __shfl_xor(mycount, off, 64);
+        if (t > mybest) { mybest = t; mycount = c; }
+    }
+    if (lane == 0) { B.red_i[1][wave] = mybest; B.red_i[0][wave] = mycount; }
+    __syncthreads();
+    int bstar = -1;
+    count = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) if (B.red_i[1][w] > bstar) { bstar = B.red_i[1][w]; count = B.red_i[0][w]; }
+    __syncthreads();
+    return bstar;
+}
+
+// The n gathered keys of one chunk (all TEPs of a sum range): sort into visit order, evaluate in parallel, apply
+// the sequential rules.  Returns 0 = no rule fired (B.j / B.nlive advanced), 1 = stopped (stop / ntep set),
+// 2 = a run of more than kPbMaxTie equal sums (frame goes to the list replay).
+template <int NT, int CAP, bool PROF>
+__device__ int pb_process_chunk(PbBlockLds<NT, CAP> &B, const uchar4 *__restrict__ tab, const PbParams &P, const PbFrame &Fr,
+                                u64 d0, int n, int tid, int &stop, int &ntep)
+{
+    constexpr int W = NT / 64;
+    SearchLds &L = B.s;
+    const int lane = tid & 63, wave = tid >> 6;
+    int npow = 2;
+    while (npow < n) npow <<= 1;
+    for (int i = n + tid; i < npow; i += NT) B.keys[i] = ~0ull;
+    __syncthreads();
+    // ---- bitonic sort, ascending
+    for (int k = 2; k <= npow; k <<= 1)
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int i = tid; i < (npow >> 1); i += NT) {
+                const int a = ((i & ~(jj - 1)) << 1) | (i & (jj - 1)), b = a | jj;
+                const u64 x = B.keys[a], yv = B.keys[b];
+                if ((x > yv) == ((a & k) == 0)) { B.keys[a] = yv; B.keys[b] = x; }
+            }
+            __syncthreads();
+        }
+    PB_STAMP(kProfSort);
+    // ---- equal sums: list order (pb_visit_less); one thread per run of equal sums
+    for (int i = tid; i + 1 < n; i += NT) {
+        const unsigned si = (unsigned)(B.keys[i] >> 32);
+        if ((i == 0 || (unsigned)(B.keys[i - 1] >> 32) != si) && (unsigned)(B.keys[i + 1] >> 32) == si) {
+            int g = 2;
+            while (i + g < n && g <= kPbMaxTie && (unsigned)(B.keys[i + g] >> 32) == si) ++g;
+            if (g > kPbMaxTie) { B.degenerate = 1; continue; }
+            for (int a = 1; a < g; ++a) {
+                const u64 ka = B.keys[i + a];
+                const PbTep ta = pb_tep(tab, (int)(unsigned)ka);
+                int b = a;
+                while (b > 0 && pb_visit_less(L.w, ta, pb_tep(tab, (int)(unsigned)B.keys[i + b - 1]))) { B.keys[i + b] = B.keys[i + b - 1]; --b; }
+                B.keys[i + b] = ka;
+            }
+        }
+    }
+    if (tid == 0) { B.gstop = 0x7FFFFFFF; B.reason = 0; B.ones = 0; B.nev = 0; B.nnb = 0; B.lnb = -1; }
+    __syncthreads();
+    PB_STAMP(kProfTie);
+    if (B.degenerate) return 2;
+    // ---- evaluate: thread t owns the entries [t per, (t+1) per) of the sorted chunk
+    const int per = (n + NT - 1) / NT;
+    const int i0 = tid * per, i1 = (i0 + per) < n ? (i0 + per) : n;
+    float tmin = __builtin_inff();
+    int tdel = 0;
+    for (int i = i0; i < i1; ++i) {
+        const u64 key = B.keys[i];
+        const PbTep t = pb_tep(tab, (int)(unsigned)key);
+        u64 D, E;
+        pb_apply(L, t, d0, D, E);
+        const float c = tep_cost(L, __uint_as_float((unsigned)(key >> 32)), D);
+        B.cost[i] = c;
+        tmin = __builtin_fminf(tmin, c);
+        tdel += pb_delta(t, P.order);
+    }
+    // exclusive scans over the threads: min of the costs / sum of the frontier growth before my entries
+    const float imin = wave_incl_min(tmin, lane);
+    const int iadd = wave_incl_add(tdel, lane);
+    if (lane == 63) { B.red_f[0][wave] = imin; B.red_i[0][wave] = iadd; }
+    __syncthreads();
+    float before = __shfl_up(imin, 1, 64);
+    if (lane == 0) before = __builtin_inff();
+    int nlb = iadd - tdel, tot_del = 0;
+    for (int w = 0; w < W; ++w) {
+        if (w < wave) { before = __builtin_fminf(before, B.red_f[0][w]); nlb += B.red_i[0][w]; }
+        tot_del += B.red_i[0][w];
+    }
+    before = __builtin_fminf(before, B.best);
+    nlb += B.nlive;
+    PB_STAMP(kProfEval1);
+    // ---- the sequential rules on my entries, assuming no earlier stop
+    int ones = 0, nev = 0, nnb = 0, lnb = -1, lstop = 0x7FFFFFFF, lreason = 0;
+    for (int i = i0; i < i1; ++i) {
+        const u64 key = B.keys[i];
+        const float rs = __uint_as_float((unsigned)(key >> 32)), c = B.cost[i];
+        const PbTep t = pb_tep(tab, (int)(unsigned)key);
+        ones += nlb == 1;
+        nlb += pb_delta(t, P.order);
+        float w1;
+        if (pb_not_promising(rs, before, Fr, P.c4, B.cdfA, B.cdfH, w1)) { lstop = i; lreason = 1; break; }
+        ++nev;
+        if (c < before) {
+            before = c; lnb = i; ++nnb;
+            u64 D, E;
+            pb_apply(L, t, d0, D, E);
+            if (pb_success(D, w1, B.q, Fr)) { lstop = i; lreason = 2; break; }
+        }
+    }
+    if (lstop != 0x7FFFFFFF) atomicMin(&B.gstop, lstop);
+    __syncthreads();
+    PB_STAMP(kProfEval2);
+    const int gstop = B.gstop;
+    if (i0 < i1 && i0 <= gstop) {     // my entries lie before (or contain) the first stop: they count
+        atomicAdd(&B.ones, ones); atomicAdd(&B.nev, nev); atomicAdd(&B.nnb, nnb);
+        if (lnb >= 0) atomicMax(&B.lnb, lnb);
+        if (lstop == gstop) B.reason = lreason;
+    }
+    __syncthreads();
+    if (lnb >= 0 && lnb == B.lnb && i0 <= gstop) {   // the last improvement before the stop is mine
+        const PbTep t = pb_tep(tab, (int)(unsigned)B.keys[lnb]);
+        u64 D, E;
+        pb_apply(L, t, d0, D, E);
+        B.best = B.cost[lnb]; B.bestD = D; B.bestE = E; B.bestidx = B.j + lnb + 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int npop = gstop != 0x7FFFFFFF ? gstop + 1 : n;
+        B.cmp += 2 * npop - B.ones; B.suc1 += B.nev; B.suc2 += B.nnb;
+    }
+    if constexpr (PROF) { if (tid == 0) B.prof[kProfChunks] += 1; }
+    if (gstop != 0x7FFFFFFF) { stop = B.reason; ntep = B.j + gstop + 1; __syncthreads(); PB_STAMP(kProfCombine); return 1; }
+    __syncthreads();
+    if (tid == 0) { B.j += n; B.nlive += tot_del; }
+    __syncthreads();
+    PB_STAMP(kProfCombine);
+    return 0;
+}
+
+// search state handed from the stage-A kernel to the stage-B kernel
+struct PbCarry {
+    float lo, best;
+    int j, nlive, cmp, suc1, suc2, bestidx;
+    u64 bestD, bestE;
+};
+
+// per-frame set-up of the workgroup kernels: wavefront 0 prepares the frame, all wavefronts build the byte LUTs
+template <int NT, int CAP>
+__device__ __forceinline__ SearchFrame pb_block_setup(PbBlockLds<NT, CAP> &B, const float *__restrict__ y, long long src, long long f,
+                                                      const unsigned char *__restrict__ perm_in, const u64 *__restrict__ parity_in,
+                                                      const PbParams &P, const double *__restrict__ coef, int lane, int wave)
+{
+    SearchLds &L = B.s;
+    SearchFrame S{};
+    if (wave == 0) S = search_prepare_regs<false>(L, y, src, perm_in[f * 128 + lane], perm_in[f * 128 + 64 + lane], parity_in[f * 64 + lane], lane);
+    __syncthreads();
+    for (int b = wave; b < 8; b += NT / 64) build_byte_luts<1>(L.lut + b, &L.w[64 + 8 * b], lane);
+    if (wave == 0) {
+        const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, coef, P.c4, P.order, P.nmax, lane);
+        if (lane == 0) { B.fr = Fr; B.d0 = S.d0; B.degenerate = 0; }
+    }
+    __syncthreads();
+    return S;
+}
+
+// Stage A of a frame of list A: the TEPs with sum <= |y'_0| (1e3 of them typically), candidates pruned per weight
+// class, chunks split by a histogram when the bound holds more than CAP TEPs.  A frame on which no rule fires
+// here goes on to list C with its search state (pb_heavy_kernel), massive ties to list B (list replay).
+template <int NT, int CAP, bool PROF>
 __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                       const unsigned char *__restrict__ perm_in,
                                                       const u64 *__restrict__ parity_in, PbParams P,
                                                       const double *__restrict__ cdf_half, const double *__restrict__ coef,
                                                       const uchar4 *__restrict__ tab, int *__restrict__ ctl,
-                                                      const int *__restrict__ listA, int *__restrict__ listB, PbOut O)
+                                                      const int *__restrict__ listA, int *__restrict__ listB,
+                                                      int *__restrict__ listC, PbCarry *__restrict__ carry, PbOut O,
+                                                      unsigned long long *__restrict__ prof_out)
 {
-    constexpr int W = NT / 64;
     __shared__ PbBlockLds<NT, CAP> B;
     SearchLds &L = B.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nlist = ctl[1];
     if (tid < 65) B.cdfH[tid] = cdf_half[tid];
+    if constexpr (PROF) { if (tid < 16) B.prof[tid] = 0; if (tid == 0) B.prof_last = __builtin_amdgcn_s_memtime(); }
 
     for (;;) {
         __syncthreads();
@@ -427,35 +654,26 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
         if (tk >= nlist) break;
         const long long f = listA[tk];
         const long long src = index ? index[f] : f;
-        SearchFrame S{};
-        if (wave == 0) S = search_prepare_regs<false>(L, y, src, perm_in[f * 128 + lane], perm_in[f * 128 + 64 + lane], parity_in[f * 64 + lane], lane);
-        __syncthreads();
-        // byte LUTs: two per wavefront (W = 4), |y'| is in place
-        for (int b = wave; b < 8; b += W) build_byte_luts<1>(L.lut + b, &L.w[64 + 8 * b], lane);
-        if (wave == 0) {
-            const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, coef, P.c4, P.order, P.nmax, lane);
-            if (lane == 0) {
-                B.fr = Fr; B.d0 = S.d0;
-                B.lo = -1.0f; B.theta_i = 0; B.hi_cur = L.w[0];
-                B.j = 0; B.nlive = 1; B.cmp = 0; B.suc1 = 0; B.suc2 = 0; B.bestidx = 0;
-                B.bestD = S.d0; B.bestE = 0; B.degenerate = 0;
-            }
+        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, coef, lane, wave);
+        if (tid == 0) {
+            B.lo = -1.0f; B.hi_cur = L.w[0];
+            B.j = 0; B.nlive = 1; B.cmp = 0; B.suc1 = 0; B.suc2 = 0; B.bestidx = 0;
+            B.bestD = B.d0; B.bestE = 0;
+            B.best = tep_cost(L, 0.0f, B.d0);
         }
         __syncthreads();
-        if (tid == 0) B.best = tep_cost(L, 0.0f, B.d0);
-        __syncthreads();
+        PB_STAMP(kProfSetup);
         const PbFrame Fr = B.fr;
         const u64 d0 = B.d0;
-        int stop = 0, ntep = P.nmax;
+        const float theta = L.w[0];
+        int stop = 0, ntep = P.nmax, state = 0;   // state: 0 = searching, 1 = a rule fired, 2 = hand the frame to the list replay
 
-        for (;;) {   // one chunk of the visit order per trip
+        for (;;) {
             const float lo = B.lo, hi = B.hi_cur;
-            const int theta_i = B.theta_i;
-            const float theta = theta_i == 0 ? L.w[0] : __builtin_inff();
+            if (!(lo < theta)) break;
             int n1, n2, n3;
             pb_candidates(L, hi, P.order, lane, n1, n2, n3);
             const int total = n1 + n2 + n3;
-            // ---- pass A: how many TEPs in (lo, hi], smallest and largest sum
             int cnt = 0;
             float mn = __builtin_inff(), mx = -1.0f;
             for (int i = tid; i < total; i += NT) {
@@ -463,77 +681,38 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
                 pb_cand(tab, L.w, i, n1, n2, id, s);
                 if (s > lo && s <= hi) { ++cnt; mn = __builtin_fminf(mn, s); mx = __builtin_fmaxf(mx, s); }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                cnt += __shfl_xor(cnt, off, 64);
-                mn = __builtin_fminf(mn, __shfl_xor(mn, off, 64));
-                mx = __builtin_fmaxf(mx, __shfl_xor(mx, off, 64));
-            }
-            if (lane == 0) { B.red_i[0][wave] = cnt; B.red_f[0][wave] = mn; B.red_f[1][wave] = mx; }
-            __syncthreads();
-            cnt = 0; mn = __builtin_inff(); mx = -1.0f;
-#pragma unroll
-            for (int w = 0; w < W; ++w) { cnt += B.red_i[0][w]; mn = __builtin_fminf(mn, B.red_f[0][w]); mx = __builtin_fmaxf(mx, B.red_f[1][w]); }
-            __syncthreads();
-            if (cnt == 0) {
-                if (hi < theta) { if (tid == 0) { B.lo = hi; B.hi_cur = theta; } }
-                else if (theta_i == 1) break;                                    // every TEP visited, no rule fired
-                else if (tid == 0) { B.lo = lo > theta ? lo : theta; B.theta_i = 1; B.hi_cur = __builtin_inff(); }
+            pb_reduce3(B, cnt, mn, mx, lane, wave);
+            PB_STAMP(kProfPassA);
+            if (cnt == 0) {   // nothing (left) below the bound: next range
+                if (tid == 0) { B.lo = hi; B.hi_cur = theta; }
                 __syncthreads();
                 continue;
             }
             const bool use_hist = cnt > CAP;
             float scale = 0.0f;
+            int bstar = kPbBins;
             if (use_hist) {
                 scale = (float)kPbBins / (mx - mn);
-                if (!(mn < mx) || !(scale < 3.0e38f)) {   // > CAP equal (or denormally close) sums
-                    if (tid == 0) B.degenerate = 1;
-                    __syncthreads();
-                    break;
-                }
+                if (!(mn < mx) || !(scale < 3.0e38f)) { state = 2; break; }   // > CAP equal (or denormally close) sums
                 for (int b = tid; b < kPbBins; b += NT) B.hist[b] = 0;
                 __syncthreads();
                 for (int i = tid; i < total; i += NT) {
                     int id; float s;
                     pb_cand(tab, L.w, i, n1, n2, id, s);
-                    if (s > lo && s <= hi) {
-                        const int bin = (int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1));
-                        atomicAdd(&B.hist[bin], 1);
-                    }
+                    if (s > lo && s <= hi) atomicAdd(&B.hist[(int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1))], 1);
                 }
                 __syncthreads();
-                // largest bin whose cumulative count still fits the chunk
-                constexpr int PERB = kPbBins / NT;
-                int local = 0;
-#pragma unroll
-                for (int q = 0; q < PERB; ++q) local += B.hist[tid * PERB + q];
-                const int incl = wave_incl_add(local, lane);
-                if (lane == 63) B.red_i[0][wave] = incl;
-                __syncthreads();
-                int run = incl - local;
-                for (int w = 0; w < wave; ++w) run += B.red_i[0][w];
-                int mybest = -1;
-#pragma unroll
-                for (int q = 0; q < PERB; ++q) { run += B.hist[tid * PERB + q]; if (run <= CAP) mybest = tid * PERB + q; }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) { const int t = __shfl_xor(mybest, off, 64); mybest = t > mybest ? t : mybest; }
-                if (lane == 0) B.red_i[1][wave] = mybest;
-                __syncthreads();
-                int bstar = -1;
-#pragma unroll
-                for (int w = 0; w < W; ++w) bstar = B.red_i[1][w] > bstar ? B.red_i[1][w] : bstar;
-                __syncthreads();
+                int dummy;
+                bstar = pb_pick_bins(B, -1, dummy, tid, lane, wave);
                 if (bstar < 0) {   // the first bin alone is too large: zoom into it
                     if (tid == 0) B.hi_cur = mn + (mx - mn) * (1.0f / (float)kPbBins);
                     __syncthreads();
                     continue;
                 }
-                if (tid == 0) B.bstar = bstar;
             }
-            // ---- gather the chunk
+            PB_STAMP(kProfHist);
             if (tid == 0) B.nkeys = 0;
             __syncthreads();
-            const int bstar = use_hist ? B.bstar : kPbBins;
             for (int i = tid; i < total; i += NT) {
                 int id; float s;
                 pb_cand(tab, L.w, i, n1, n2, id, s);
@@ -542,128 +721,187 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
                 if (sel) B.keys[atomicAdd(&B.nkeys, 1)] = ((u64)__float_as_uint(s) << 32) | (unsigned)id;
             }
             __syncthreads();
+            PB_STAMP(kProfGather);
             const int n = B.nkeys;
-            if (n == 0) {   // (cannot happen: the bin of the smallest sum is never empty) -- zoom rather than trust it
-                if (tid == 0) B.hi_cur = mn + (mx - mn) * (1.0f / (float)kPbBins);
-                __syncthreads();
-                continue;
-            }
-            int npow = 2;
-            while (npow < n) npow <<= 1;
-            for (int i = n + tid; i < npow; i += NT) B.keys[i] = ~0ull;
-            __syncthreads();
-            // ---- bitonic sort, ascending
-            for (int k = 2; k <= npow; k <<= 1)
-                for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                    for (int i = tid; i < (npow >> 1); i += NT) {
-                        const int a = ((i & ~(jj - 1)) << 1) | (i & (jj - 1)), b = a | jj;
-                        const u64 x = B.keys[a], yv = B.keys[b];
-                        if ((x > yv) == ((a & k) == 0)) { B.keys[a] = yv; B.keys[b] = x; }
-                    }
-                    __syncthreads();
-                }
-            // ---- equal sums: list order (pb_visit_less); one thread per run of equal sums
-            for (int i = tid; i + 1 < n; i += NT) {
-                const unsigned si = (unsigned)(B.keys[i] >> 32);
-                if ((i == 0 || (unsigned)(B.keys[i - 1] >> 32) != si) && (unsigned)(B.keys[i + 1] >> 32) == si) {
-                    int g = 2;
-                    while (i + g < n && g <= kPbMaxTie && (unsigned)(B.keys[i + g] >> 32) == si) ++g;
-                    if (g > kPbMaxTie) { B.degenerate = 1; continue; }
-                    for (int a = 1; a < g; ++a) {
-                        const u64 ka = B.keys[i + a];
-                        const PbTep ta = pb_tep(tab, (int)(unsigned)ka);
-                        int b = a;
-                        while (b > 0 && pb_visit_less(L.w, ta, pb_tep(tab, (int)(unsigned)B.keys[i + b - 1]))) { B.keys[i + b] = B.keys[i + b - 1]; --b; }
-                        B.keys[i + b] = ka;
-                    }
-                }
-            }
-            if (tid == 0) { B.gstop = 0x7FFFFFFF; B.reason = 0; B.ones = 0; B.nev = 0; B.nnb = 0; B.lnb = -1; }
-            __syncthreads();
-            if (B.degenerate) break;
-            // ---- evaluate: thread t owns the entries [t per, (t+1) per) of the sorted chunk
-            const int per = (n + NT - 1) / NT;
-            const int i0 = tid * per, i1 = (i0 + per) < n ? (i0 + per) : n;
-            float tmin = __builtin_inff();
-            int tdel = 0;
-            for (int i = i0; i < i1; ++i) {
-                const u64 key = B.keys[i];
-                const PbTep t = pb_tep(tab, (int)(unsigned)key);
-                u64 D, E;
-                pb_apply(L, t, d0, D, E);
-                const float c = tep_cost(L, __uint_as_float((unsigned)(key >> 32)), D);
-                B.cost[i] = c;
-                tmin = __builtin_fminf(tmin, c);
-                tdel += pb_delta(t, P.order);
-            }
-            // exclusive scans over the threads: min of the costs / sum of the frontier growth before my entries
-            const float imin = wave_incl_min(tmin, lane);
-            const int iadd = wave_incl_add(tdel, lane);
-            if (lane == 63) { B.red_f[0][wave] = imin; B.red_i[0][wave] = iadd; }
-            __syncthreads();
-            float before = __shfl_up(imin, 1, 64);
-            if (lane == 0) before = __builtin_inff();
-            int nlb = iadd - tdel, tot_del = 0;
-            for (int w = 0; w < W; ++w) {
-                if (w < wave) { before = __builtin_fminf(before, B.red_f[0][w]); nlb += B.red_i[0][w]; }
-                tot_del += B.red_i[0][w];
-            }
-            before = __builtin_fminf(before, B.best);
-            nlb += B.nlive;
-            // ---- the sequential rules on my entries, assuming no earlier stop
-            int ones = 0, nev = 0, nnb = 0, lnb = -1, lstop = 0x7FFFFFFF, lreason = 0;
-            for (int i = i0; i < i1; ++i) {
-                const u64 key = B.keys[i];
-                const float rs = __uint_as_float((unsigned)(key >> 32)), c = B.cost[i];
-                const PbTep t = pb_tep(tab, (int)(unsigned)key);
-                ones += nlb == 1;
-                nlb += pb_delta(t, P.order);
-                float w1;
-                if (pb_not_promising(rs, before, Fr, P.c4, B.cdfA, B.cdfH, w1)) { lstop = i; lreason = 1; break; }
-                ++nev;
-                if (c < before) {
-                    before = c; lnb = i; ++nnb;
-                    u64 D, E;
-                    pb_apply(L, t, d0, D, E);
-                    if (pb_success(D, w1, B.q, Fr)) { lstop = i; lreason = 2; break; }
-                }
-            }
-            if (lstop != 0x7FFFFFFF) atomicMin(&B.gstop, lstop);
-            __syncthreads();
-            const int gstop = B.gstop;
-            if (i0 < i1 && i0 <= gstop) {     // my entries lie before (or contain) the first stop: they count
-                atomicAdd(&B.ones, ones); atomicAdd(&B.nev, nev); atomicAdd(&B.nnb, nnb);
-                if (lnb >= 0) atomicMax(&B.lnb, lnb);
-                if (lstop == gstop) B.reason = lreason;
-            }
-            __syncthreads();
-            if (lnb >= 0 && lnb == B.lnb && i0 <= gstop) {   // the last improvement before the stop is mine
-                const PbTep t = pb_tep(tab, (int)(unsigned)B.keys[lnb]);
-                u64 D, E;
-                pb_apply(L, t, d0, D, E);
-                B.best = B.cost[lnb]; B.bestD = D; B.bestE = E; B.bestidx = B.j + lnb + 1;
-            }
-            __syncthreads();
+            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, tid, stop, ntep);
+            if (state) break;
             if (tid == 0) {
-                const int npop = gstop != 0x7FFFFFFF ? gstop + 1 : n;
-                B.cmp += 2 * npop - B.ones; B.suc1 += B.nev; B.suc2 += B.nnb;
-            }
-            if (gstop != 0x7FFFFFFF) { stop = B.reason; ntep = B.j + gstop + 1; __syncthreads(); break; }
-            if (tid == 0) {
-                B.j += n; B.nlive += tot_del;
                 if (use_hist) B.lo = __uint_as_float((unsigned)(B.keys[n - 1] >> 32));
-                else { B.lo = hi; if (hi < theta) B.hi_cur = theta; }
+                else { B.lo = hi; B.hi_cur = theta; }
             }
             __syncthreads();
         }
         __syncthreads();
-        if (B.degenerate) {   // massive ties: the literal list replay decodes this frame
+        if (state == 2) {   // massive ties: the literal list replay decodes this frame
+            if (tid == 0) listB[atomicAdd(&ctl[3], 1)] = (int)f;
+            continue;
+        }
+        if (state == 0 && P.order > 1) {   // no rule fired below |y'_0|: the search goes on over ALL remaining TEPs
+            if (tid == 0) {
+                PbCarry c;
+                c.lo = B.lo; c.best = B.best; c.j = B.j; c.nlive = B.nlive; c.cmp = B.cmp; c.suc1 = B.suc1; c.suc2 = B.suc2;
+                c.bestidx = B.bestidx; c.bestD = B.bestD; c.bestE = B.bestE;
+                carry[f] = c;
+                listC[atomicAdd(&ctl[5], 1)] = (int)f;
+            }
+            continue;
+        }
+        if (wave == 0)
+            pb_write(L, S, O, f, lane, B.bestE, B.bestD, B.best, B.bestidx, ntep, B.cmp, B.suc1, B.suc2, stop);
+        if constexpr (PROF) { if (tid == 0) B.prof[kProfFrames] += 1; }
+        PB_STAMP(kProfFinish);
+    }
+    if constexpr (PROF) { __syncthreads(); if (tid < 16) atomicAdd(&prof_out[tid], B.prof[tid]); }
+}
+
+// Stage B of a frame of list C: every TEP with a sum above |y'_0|.  The 43 744 sums are computed once into a
+// per-workgroup global array, histogrammed (1024 bins), and counting-sorted by bin into a second global array;
+// a chunk is then a run of whole bins = a contiguous slice of that array.  A full scan is 3 passes over the
+// TEP table plus ~11 chunks.
+template <int NT, int CAP, bool PROF>
+__global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                      const unsigned char *__restrict__ perm_in,
+                                                      const u64 *__restrict__ parity_in, PbParams P,
+                                                      const double *__restrict__ cdf_half, const double *__restrict__ coef,
+                                                      const uchar4 *__restrict__ tab, float *__restrict__ cache_all,
+                                                      u64 *__restrict__ binned_all, int *__restrict__ ctl,
+                                                      const int *__restrict__ listC, int *__restrict__ listB,
+                                                      const PbCarry *__restrict__ carry, PbOut O,
+                                                      unsigned long long *__restrict__ prof_out)
+{
+    constexpr int W = NT / 64;
+    __shared__ PbBlockLds<NT, CAP> B;
+    SearchLds &L = B.s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nlist = ctl[5];
+    float *cache = cache_all + (size_t)blockIdx.x * kPbTabSize;
+    u64 *binned = binned_all + (size_t)blockIdx.x * kPbTabSize;
+    const int nall = P.order == 2 ? kPbTriples0 : kPbTabSize;
+    if (tid < 65) B.cdfH[tid] = cdf_half[tid];
+    if constexpr (PROF) { if (tid < 16) B.prof[tid] = 0; if (tid == 0) B.prof_last = __builtin_amdgcn_s_memtime(); }
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) B.ticket = atomicAdd(&ctl[6], 1);
+        __syncthreads();
+        const int tk = B.ticket;
+        if (tk >= nlist) break;
+        const long long f = listC[tk];
+        const long long src = index ? index[f] : f;
+        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, coef, lane, wave);
+        if (tid == 0) {
+            const PbCarry c = carry[f];
+            B.lo = c.lo; B.best = c.best; B.j = c.j; B.nlive = c.nlive; B.cmp = c.cmp; B.suc1 = c.suc1; B.suc2 = c.suc2;
+            B.bestidx = c.bestidx; B.bestD = c.bestD; B.bestE = c.bestE;
+        }
+        __syncthreads();
+        PB_STAMP(kProfSetup);
+        const PbFrame Fr = B.fr;
+        const u64 d0 = B.d0;
+        const float lo = B.lo;    // = |y'_0|
+        int stop = 0, ntep = P.nmax, state = 0;
+        // ---- pass 1: all sums once (id == table index when every class is complete)
+        int cnt = 0;
+        float mn = __builtin_inff(), mx = -1.0f;
+        for (int i = tid; i < nall; i += NT) {
+            int id; float s;
+            pb_cand(tab, L.w, i, 64, kPbTriples0 - kPbPairs0, id, s);
+            cache[i] = s;
+            if (s > lo) { ++cnt; mn = __builtin_fminf(mn, s); mx = __builtin_fmaxf(mx, s); }
+        }
+        pb_reduce3(B, cnt, mn, mx, lane, wave);
+        PB_STAMP(kProfFill);
+        if (cnt > 0 && cnt <= CAP) {   // one chunk
+            if (tid == 0) B.nkeys = 0;
+            __syncthreads();
+            for (int i = tid; i < nall; i += NT) {
+                const float s = cache[i];
+                if (s > lo) B.keys[atomicAdd(&B.nkeys, 1)] = ((u64)__float_as_uint(s) << 32) | (unsigned)i;
+            }
+            __syncthreads();
+            PB_STAMP(kProfGather);
+            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, B.nkeys, tid, stop, ntep);
+        } else if (cnt > CAP) {
+            const float scale = (float)kPbBins / (mx - mn);
+            if (!(mn < mx) || !(scale < 3.0e38f)) state = 2;
+            else {
+                // ---- pass 2: histogram; offsets by an exclusive scan over the bins
+                for (int b = tid; b <= kPbBins; b += NT) { if (b < kPbBins) B.hist[b] = 0; B.binoff[b] = 0; }
+                __syncthreads();
+                for (int i = tid; i < nall; i += NT) {
+                    const float s = cache[i];
+                    if (s > lo) atomicAdd(&B.hist[(int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1))], 1);
+                }
+                __syncthreads();
+                {
+                    constexpr int PERB = (kPbBins + NT - 1) / NT;
+                    int local = 0;
+#pragma unroll
+                    for (int q = 0; q < PERB; ++q) { const int b = tid * PERB + q; local += b < kPbBins ? B.hist[b] : 0; }
+                    const int incl = wave_incl_add(local, lane);
+                    if (lane == 63) B.red_i[0][wave] = incl;
+                    __syncthreads();
+                    int run = incl - local;
+                    for (int w = 0; w < wave; ++w) run += B.red_i[0][w];
+#pragma unroll
+                    for (int q = 0; q < PERB; ++q) {
+                        const int b = tid * PERB + q;
+                        if (b < kPbBins) { B.binoff[b] = run; run += B.hist[b]; }
+                    }
+                    if (tid == NT - 1) B.binoff[kPbBins] = run;
+                    __syncthreads();
+                    for (int b = tid; b < kPbBins; b += NT) B.hist[b] = 0;    // now the fill counters of the bins
+                    __syncthreads();
+                }
+                PB_STAMP(kProfHist);
+                // ---- pass 3: counting sort by bin into the global array
+                for (int i = tid; i < nall; i += NT) {
+                    const float s = cache[i];
+                    if (s > lo) {
+                        const int bin = (int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1));
+                        binned[B.binoff[bin] + atomicAdd(&B.hist[bin], 1)] = ((u64)__float_as_uint(s) << 32) | (unsigned)i;
+                    }
+                }
+                __syncthreads();   // (workgroup-scope release/acquire: the slices below are read by other threads)
+                PB_STAMP(kProfScatter);
+                // ---- chunks: the longest run of whole bins that fits
+                int bprev = -1;
+                while (state == 0 && bprev < kPbBins - 1) {
+                    const int base = B.binoff[bprev + 1];
+                    int mybest = -1;
+                    for (int b = tid; b < kPbBins; b += NT)
+                        if (b > bprev && B.binoff[b + 1] - base <= CAP) mybest = b > mybest ? b : mybest;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) { const int t = __shfl_xor(mybest, off, 64); mybest = t > mybest ? t : mybest; }
+                    if (lane == 0) B.red_i[1][wave] = mybest;
+                    __syncthreads();
+                    int bnext = -1;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) bnext = B.red_i[1][w] > bnext ? B.red_i[1][w] : bnext;
+                    __syncthreads();
+                    if (bnext < 0) { state = 2; break; }       // one bin holds more than a chunk: massive ties
+                    const int n = B.binoff[bnext + 1] - base;
+                    if (n > 0) {
+                        for (int i = tid; i < n; i += NT) B.keys[i] = binned[base + i];
+                        __syncthreads();
+                        PB_STAMP(kProfGather);
+                        state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, tid, stop, ntep);
+                    }
+                    bprev = bnext;
+                }
+            }
+        }
+        __syncthreads();
+        if (state == 2) {
             if (tid == 0) listB[atomicAdd(&ctl[3], 1)] = (int)f;
             continue;
         }
         if (wave == 0)
             pb_write(L, S, O, f, lane, B.bestE, B.bestD, B.best, B.bestidx, ntep, B.cmp, B.suc1, B.suc2, stop);
+        if constexpr (PROF) { if (tid == 0) B.prof[kProfFrames] += 1; }
+        PB_STAMP(kProfFinish);
     }
+    if constexpr (PROF) { __syncthreads(); if (tid < 16) atomicAdd(&prof_out[tid], B.prof[tid]); }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -878,7 +1116,12 @@ static int stream_ws_pb(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int64_t sp
         (void)hipFree(w.d_pb_list); w.d_pb_list = nullptr; w.pb_cap = 0;
         if (!w.d_pb_ctl && hipMalloc((void **)&w.d_pb_ctl, sizeof(int) * kPbCtlInts) != hipSuccess)
             return fail(LDPC_E_NOMEM, "PB-OSD control words could not be allocated");
-        if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * 2 * (size_t)frames) != hipSuccess)
+        if (!w.d_pb_cache && (hipMalloc((void **)&w.d_pb_cache, sizeof(float) * (size_t)kPbTabSize * kPbHeavyGrid) != hipSuccess ||
+                              hipMalloc(&w.d_pb_binned, sizeof(u64) * (size_t)kPbTabSize * kPbHeavyGrid) != hipSuccess))
+            return fail(LDPC_E_NOMEM, "PB-OSD sum arrays could not be allocated");
+        (void)hipFree(w.d_pb_carry); w.d_pb_carry = nullptr;
+        if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * 3 * (size_t)frames) != hipSuccess ||
+            hipMalloc(&w.d_pb_carry, sizeof(PbCarry) * (size_t)frames) != hipSuccess)
             return fail(LDPC_E_NOMEM, "PB-OSD frame lists for %lld frames could not be allocated", (long long)frames);
         w.pb_cap = frames;
     }
@@ -911,15 +1154,41 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     pp.c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)p->snr_db / 10.0)));    // -4 * noise_variance, pb_testing.py:50-52
     const int mode = (p->reserved & 4) ? 2 : ((p->reserved & 2) ? 1 : 0);
     PbOut O{reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep, reinterpret_cast<int *>(p->d_aux)};
-    int *listA = w->d_pb_list, *listB = w->d_pb_list + w->pb_cap;
+    int *listA = w->d_pb_list, *listB = w->d_pb_list + w->pb_cap, *listC = w->d_pb_list + 2 * w->pb_cap;
     LDPC_HIP(hipMemsetAsync(w->d_pb_ctl, 0, sizeof(int) * kPbCtlInts, s));
     const int64_t want = (F + 3) / 4;
     const unsigned g1 = (unsigned)(want < 1 ? 1 : (want < 8192 ? want : 8192));
     hipLaunchKernelGGL(pb_singles_kernel, dim3(g1), dim3(256), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
                        st->d_cdf_half, st->d_coef, w->d_pb_ctl, listA, listB, O);
-    const unsigned g2 = (unsigned)(F < 1024 ? F : 1024);
-    hipLaunchKernelGGL((pb_block_kernel<256, 2048>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half,
-                       st->d_coef, st->d_pb_tab, w->d_pb_ctl, listA, listB, O);
+    const unsigned g2 = (unsigned)(F < 1024 ? F : 1024), g2b = (unsigned)(F < kPbHeavyGrid ? F : kPbHeavyGrid);
+    PbCarry *carry = reinterpret_cast<PbCarry *>(w->d_pb_carry);
+    u64 *binned = reinterpret_cast<u64 *>(w->d_pb_binned);
+    static const bool profile = getenv("LDPC_PB_PROFILE") != nullptr;   // diagnostic build of the two workgroup kernels
+    if (!profile) {
+        hipLaunchKernelGGL((pb_block_kernel<256, 2048, false>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
+                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, O, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, false>), dim3(g2b), dim3(1024), 0, s, d_y, d_index, d_perm, d_parity, pp,
+                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_cache, binned, w->d_pb_ctl, listC, listB, carry, O,
+                           (unsigned long long *)nullptr);
+    } else {
+        static unsigned long long *d_prof = nullptr;
+        if (!d_prof) LDPC_HIP(hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 32));
+        LDPC_HIP(hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 32, s));
+        hipLaunchKernelGGL((pb_block_kernel<256, 2048, true>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
+                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, O, d_prof);
+        hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, true>), dim3(g2b), dim3(1024), 0, s, d_y, d_index, d_perm, d_parity, pp,
+                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_cache, binned, w->d_pb_ctl, listC, listB, carry, O, d_prof + 16);
+        unsigned long long h[32];
+        LDPC_HIP(hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, s));
+        LDPC_HIP(hipStreamSynchronize(s));
+        static const char *names[14] = {"setup", "passA", "hist", "gather", "sort", "tie", "eval1", "eval2", "combine", "fill", "scatter",
+                                        "finish", "FRAMES", "CHUNKS"};
+        for (int k = 0; k < 2; ++k) {
+            fprintf(stderr, "[LDPC_PB_PROFILE] %s kernel, cycles of thread 0 summed over workgroups:", k ? "stage-B" : "stage-A");
+            for (int q = 0; q < 14; ++q) fprintf(stderr, " %s=%llu", names[q], h[16 * k + q]);
+            fprintf(stderr, "\n");
+        }
+    }
     const unsigned g3 = (unsigned)(want < kPbSeqBlocks ? (want < 1 ? 1 : want) : kPbSeqBlocks);
     hipLaunchKernelGGL(pb_seq_kernel, dim3(g3), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half, st->d_coef,
                        reinterpret_cast<PbEntry *>(w->d_pb_spill), (long long)w->pb_spill_stride, w->d_pb_ctl, listB, O);

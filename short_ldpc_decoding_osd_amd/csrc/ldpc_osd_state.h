@@ -13,12 +13,16 @@ struct StreamWs {
     u64 *d_parity = nullptr;          //                                    [cap][64]
     int64_t cap = 0;
     int *d_pb_ctl = nullptr;          // PB-OSD: frame tickets and list lengths (kPbCtlInts ints, zeroed per call)
-    int *d_pb_list = nullptr;         // PB-OSD: [2][pb_cap] frames handed on to the block kernel / the sequential kernel
+    int *d_pb_list = nullptr;         // PB-OSD: [3][pb_cap] frames handed on: list A (stage A), B (list replay), C (stage B)
+    void *d_pb_carry = nullptr;       // PB-OSD: [pb_cap] search state of the frames on list C
     int64_t pb_cap = 0;
+    float *d_pb_cache = nullptr;      // PB-OSD stage B: the 43 744 reliability sums of a frame, per workgroup
+    void *d_pb_binned = nullptr;      //                 and the same as (sum, id) keys counting-sorted by histogram bin
     void *d_pb_spill = nullptr;       // PB-OSD sequential kernel: frontier overflow [waves][stride]
     int64_t pb_spill_stride = 0;
 };
-constexpr int kPbCtlInts = 8;         // {ticket 1, list A length, ticket 2, list B length, ticket 3, -, -, -}
+constexpr int kPbCtlInts = 8;         // {-, list A length, ticket A, list B length, ticket B, list C length, ticket C, -}
+constexpr int kPbHeavyGrid = 512;     // grid of the stage-B PB kernel (each workgroup owns 171 + 342 KiB of global scratch)
 constexpr int kPbSeqBlocks = 64;      // grid of the sequential PB kernel (each of its 4 x 64 waves owns a spill area)
 
 struct OsdState {
