@@ -186,8 +186,10 @@ typedef struct ldpc_osd_params {
     float fs_tau_psc;    /* FS-OSD tau_psc, FS_OSD/globalmap.py:50 (30)                    */
     int32_t fs_reference_quirk; /* 1: keep optimal_codeword un-updated on a tau_e hit (fs_testing.py:145) */
     int32_t reserved;    /* 0; cross-check switches: bit 0 = conventional order 2 through the table-driven scan instead of
-                            the register-resident kernel; PB-OSD: bit 1 = every frame through the workgroup
-                            (sorted-chunk) kernel, bit 2 = every frame through the literal list replay       */
+                            the register-resident kernels, bit 3 = the register-resident kernel with v_readlane
+                            pairing instead of the rotation-paired persistent one; PB-OSD: bit 1 = every frame
+                            through the workgroup (sorted-chunk) kernels, bit 2 = every frame through the literal
+                            list replay                                                                       */
     void *d_aux;         /* optional DEVICE [F][4] i32, PB-OSD statistics per frame: {frontier comparisons
                             (memory_sum, pb_testing.py:122), suc counter 1 (:138), suc counter 2 (:144),
                             stop reason 0 = none / 1 = promising rule (:129) / 2 = success rule (:145)} */

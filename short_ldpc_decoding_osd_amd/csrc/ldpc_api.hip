@@ -37,13 +37,17 @@ int ldpc_ctx_create(const ldpc_code *code, int32_t device, ldpc_ctx **out)
     ldpc_ctx *ctx = new ldpc_ctx();
     ctx->device = device;
     ctx->code = *code;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
+    }
     int rc = LDPC_OK;
     do {
         if ((rc = upload(code->chk_ptr, &ctx->d_chk_ptr))) break;
         if ((rc = upload(code->chk_var, &ctx->d_chk_var))) break;
         if ((rc = upload(code->var_ptr, &ctx->d_var_ptr))) break;
         if ((rc = upload(code->var_edge, &ctx->d_var_edge))) break;
-        if ((rc = probe_dpp(&ctx->dpp_ror_up))) break;
+        if ((rc = probe_dpp(&ctx->dpp_ror_up, &ctx->dpp_wave_rol_dir))) break;
         // event pool of ldpc_pipeline_run's timing slots: created (and recorded once: the first record of an
         // event sets up its signal and is slow) here, so that decode calls never change the context
         ctx->timing = new hipEvent_t[LDPC_TIMING_SLOTS * 6]();

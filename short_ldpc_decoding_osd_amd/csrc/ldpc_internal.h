@@ -49,7 +49,7 @@ struct ldpc_code {
 };
 
 struct ldpc_ctx {
-    int device = 0;
+    int device = 0, cu_count = 256;
     ldpc_code code;
     // generic NMS tables
     int32_t *d_chk_ptr = nullptr, *d_chk_var = nullptr, *d_var_ptr = nullptr, *d_var_edge = nullptr;
@@ -58,6 +58,7 @@ struct ldpc_ctx {
     uint8_t *d_tep = nullptr;      // TEP supports, order <= 3: [43745][4] (i, j, l, weight)
     uint64_t *d_Hcols = nullptr;   // [128] column v of H as a 64-bit word (bit r = H[r][v]); n = 128, m = 64 only
     bool dpp_ror_up = true;        // probed: row_ror:n moves data towards higher lanes
+    int dpp_wave_rol_dir = 0;      // probed: wave_rol:1 -- +1 lane j receives lane j-1, -1 lane j+1, 0 unusable
     bool osd_ok = false;
     bool hosd_ok = false;
     void *osd_state = nullptr;     // ldpc::OsdState (TEP tables; per-stream workspaces behind its mutex)
@@ -76,7 +77,7 @@ int64_t hosd_pattern_teps(int nseg, const int32_t *bounds, const int32_t *patter
 // launchers (one per .hip file)
 int launch_nms(ldpc_ctx *ctx, const float *d_llr, int64_t B, int T, const float *alpha, float w_in, float w_out,
                float *d_soft, float *d_traj, uint64_t *d_hard, uint8_t *d_fail, int kernel, hipStream_t st);
-int probe_dpp(bool *ror_up);
+int probe_dpp(bool *ror_up, int *wave_rol_dir);
 int eval_and_compact(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_label, const uint8_t *d_fail, int64_t B,
                      int64_t *d_counts, int32_t *d_index, int32_t *d_count, hipStream_t st);
 

@@ -354,12 +354,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __global__ void dpp_probe_kernel(int *out)
 {
     int lane = threadIdx.x;
-    out[lane] = __builtin_amdgcn_update_dpp(0, lane, 0x121, 0xF, 0xF, true);  // row_ror:1
+    out[lane] = __builtin_amdgcn_update_dpp(0, lane, 0x121, 0xF, 0xF, true);        // row_ror:1
+    out[64 + lane] = __builtin_amdgcn_update_dpp(-1, lane, 0x134, 0xF, 0xF, false);  // wave_rol:1
 }
 
-int probe_dpp(bool *ror_up)
+int probe_dpp(bool *ror_up, int *wave_rol_dir)
 {
-    int *d = nullptr, h[64];
+    int *d = nullptr, h[128];
     LDPC_HIP(hipMalloc(&d, sizeof(h)));
     hipLaunchKernelGGL(dpp_probe_kernel, dim3(1), dim3(64), 0, 0, d);
     hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
@@ -368,6 +369,11 @@ int probe_dpp(bool *ror_up)
     if (h[1] == 0 && h[0] == 15) *ror_up = true;        // lane j received lane j-1
     else if (h[1] == 2 && h[0] == 1) *ror_up = false;   // lane j received lane j+1
     else return fail(LDPC_E_HIP, "unexpected row_ror behaviour: lane0=%d lane1=%d", h[0], h[1]);
+    // wave_rol:1 over all 64 lanes: +1 = lane j received lane j-1, -1 = lane j received lane j+1, 0 = not a rotation
+    // (then the order-2 scan keeps its v_readlane pairing)
+    int up = 1, down = 1;
+    for (int j = 0; j < 64; ++j) { up &= h[64 + j] == ((j + 63) & 63); down &= h[64 + j] == ((j + 1) & 63); }
+    *wave_rol_dir = up ? 1 : (down ? -1 : 0);
     return LDPC_OK;
 }
 

@@ -353,6 +353,173 @@ __global__ __launch_bounds__(64) void osd_search2_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// Order-2 scan, second form (the one the launcher uses when the wave_rol probe succeeded):
+//  * pairing by ROTATION: in round r = 1..32 lane l meets lane (l -+ r) mod 64, whose row of P' and weight
+//    arrive by three `wave_rol:1` DPP moves of a rotating copy -- no v_readlane (8 issue cycles each, six per
+//    round in the triangular pairing above) and no selects; rounds 1..31 cover every unordered pair once per
+//    lane, round 32 pairs l with l +- 32 and only lanes < 32 count;
+//  * persistent workgroups (one wavefront each) stride over the frames, and the global inputs of frame
+//    f + 2 grid (perm, P' row) and f + grid (channel values, addressed through its perm) are in flight while
+//    frame f is scanned, so the ~2 us of dependent global latency of the prologue is hidden;
+//  * everything else (two-stage scan with the exact prefix bound, survivor ring, rank-ordered ties) as above.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_rot1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x134, 0xF, 0xF, true); }
+
+__device__ __forceinline__ void search2r_finish_batch(const SearchLds &L, uint4 e, bool valid, int dir, const int *__restrict__ base2,
+                                                      float &best, int &bi, int &bj, u64 &bestD)
+{
+    if (!valid) return;
+    const u64 D = ((u64)e.y << 32) | e.x;
+    float acc = __uint_as_float(e.z);
+    acc = acc + lut_term<2>(L, D); acc = acc + lut_term<3>(L, D); acc = acc + lut_term<4>(L, D);
+    acc = acc + lut_term<5>(L, D); acc = acc + lut_term<6>(L, D); acc = acc + lut_term<7>(L, D);
+    if (!(acc <= best)) return;
+    const int r = (int)(e.w >> 6), l = (int)(e.w & 63), m = (l - dir * r) & 63;
+    const int ci = l < m ? l : m, cj = l < m ? m : l;
+    // equal metrics are ordered by table rank (practically never taken)
+    if (acc < best || tep2_rank(ci, cj, base2) < tep2_rank(bi, bj, base2)) { best = acc; bi = ci; bj = cj; bestD = D; }
+}
+
+__device__ __forceinline__ void search2r_device(Search2Lds &LL, const SearchFrame &S, u64 Pl, float wl, int dir,
+                                                const int *__restrict__ base2, int lane, float &best_out, int &rank_out,
+                                                u64 &D_out, u64 &E_out)
+{
+    SearchLds &L = LL.s;
+    // order 0 (rank 0, identical in every lane), then order 1: lane l owns TEP {l}
+    float best = tep_cost(L, 0.0f, S.d0);
+    int bi = -1, bj = -1;
+    u64 bestD = S.d0;
+    const u64 dP = S.d0 ^ Pl;
+    {
+        const float c = tep_cost(L, wl, dP);
+        if (c < best) { best = c; bj = lane; bestD = dP; }      // a tie keeps the lower rank (order 0)
+    }
+    float bound = wave_min_f32(best);
+    int qhead = 0, qn = 0;   // ring state (wave-uniform)
+    int plo = (int)(unsigned)Pl, phi = (int)(unsigned)(Pl >> 32), wr = __float_as_int(wl);
+    // software pipeline: the two LUT reads of round r + 1 are issued before round r is finished, so their LDS latency
+    // (bank conflicts included) overlaps the survivor bookkeeping -- at 3.5 wavefronts per SIMD nothing else hides it
+    plo = wave_rot1(plo); phi = wave_rot1(phi); wr = wave_rot1(wr);
+    u64 D = dP ^ (((u64)(unsigned)phi << 32) | (unsigned)plo);
+    float m = wl + __int_as_float(wr), t0 = lut_term<0>(L, D), t1 = lut_term<1>(L, D);
+    for (int r = 1; r <= 32; ++r) {
+        plo = wave_rot1(plo); phi = wave_rot1(phi); wr = wave_rot1(wr);          // (round 33 is computed and never used)
+        const u64 Dn = dP ^ (((u64)(unsigned)phi << 32) | (unsigned)plo);
+        const float mn = wl + __int_as_float(wr), u0 = lut_term<0>(L, Dn), u1 = lut_term<1>(L, Dn);
+        float acc = m + t0;                                                       // |y'_i| + |y'_j| (commutative), then byte 0
+        acc = acc + t1;
+        const bool keep = (r < 32 || lane < 32) && !(acc > bound);
+        const u64 km = __ballot(keep);
+        if (km) {
+            if (keep) {
+                const int slot = (qhead + qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0))) & 127;
+                LL.q[slot] = make_uint4((unsigned)D, (unsigned)(D >> 32), __float_as_uint(acc), (unsigned)(r * 64 + lane));
+            }
+            qn += __popcll(km);
+            if (qn >= 64) {
+                wave_fence();
+                search2r_finish_batch(L, LL.q[(qhead + lane) & 127], true, dir, base2, best, bi, bj, bestD);
+                qhead = (qhead + 64) & 127;
+                qn -= 64;
+                bound = wave_min_f32(best);
+                wave_fence();
+            }
+        }
+        D = Dn; m = mn; t0 = u0; t1 = u1;
+    }
+    wave_fence();
+    search2r_finish_batch(L, LL.q[(qhead + lane) & 127], lane < qn, dir, base2, best, bi, bj, bestD);
+    wave_fence();
+    int bestt = tep2_rank(bi, bj, base2);
+    u64 bestE = (bi >= 0 ? 1ull << bi : 0ull) | (bj >= 0 ? 1ull << bj : 0ull);
+    wave_argmin(best, bestt, bestD, bestE, lane);
+    best_out = best; rank_out = bestt; D_out = bestD; E_out = bestE;
+}
+
+// frames are handed out by a ticket counter (scan times differ with the number of survivors: with a static split
+// the wavefronts were alive for only 63 % of the launch); the last wavefront to leave resets the two counters, so
+// no memset precedes the launch.  tickets[0] = next frame, tickets[1] = wavefronts that have left.
+__device__ __forceinline__ long long search2r_ticket(int *__restrict__ tickets, int lane)
+{
+    int t = 0;
+    if (lane == 0) t = atomicAdd(&tickets[0], 1);
+    return __builtin_amdgcn_readfirstlane(t);
+}
+
+__global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                          const int *__restrict__ count, long long F,
+                                                          const unsigned char *__restrict__ perm_in,
+                                                          const u64 *__restrict__ parity_in, int dir,
+                                                          const int *__restrict__ base2, int *__restrict__ tickets,
+                                                          u64 *__restrict__ cw_out, float *__restrict__ metric_out,
+                                                          int *__restrict__ best_out, int *__restrict__ ntep_out)
+{
+    __shared__ Search2Lds LL;
+    SearchLds &L = LL.s;
+    const int lane = threadIdx.x;
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    // software pipeline over the frames of this workgroup: (o, P) two frames ahead, y one frame ahead
+    long long f0 = search2r_ticket(tickets, lane), f1 = search2r_ticket(tickets, lane), f2 = search2r_ticket(tickets, lane);
+    int o1a = 0, o2a = 0, o1b = 0, o2b = 0;
+    u64 Pa = 0, Pb = 0;
+    long long srca = 0, srcb = 0;
+    float y1a = 0.0f, y2a = 0.0f;
+    if (f0 < nframes) {
+        o1a = perm_in[f0 * 128 + lane]; o2a = perm_in[f0 * 128 + 64 + lane]; Pa = parity_in[f0 * 64 + lane];
+        srca = index ? index[f0] : f0;
+    }
+    if (f1 < nframes) {
+        o1b = perm_in[f1 * 128 + lane]; o2b = perm_in[f1 * 128 + 64 + lane]; Pb = parity_in[f1 * 64 + lane];
+        srcb = index ? index[f1] : f1;
+    }
+    if (f0 < nframes) { y1a = y[srca * 128 + o1a]; y2a = y[srca * 128 + o2a]; }
+    while (f0 < nframes) {
+        // issue the loads of the frames ahead (they are consumed one / two trips later) and draw the next ticket
+        const long long f3 = search2r_ticket(tickets, lane);
+        float y1b = 0.0f, y2b = 0.0f;
+        if (f1 < nframes) { y1b = y[srcb * 128 + o1b]; y2b = y[srcb * 128 + o2b]; }
+        int o1c = 0, o2c = 0;
+        u64 Pc = 0;
+        long long srcc = 0;
+        if (f2 < nframes) {
+            o1c = perm_in[f2 * 128 + lane]; o2c = perm_in[f2 * 128 + 64 + lane]; Pc = parity_in[f2 * 64 + lane];
+            srcc = index ? index[f2] : f2;
+        }
+        // ---- frame f0
+        SearchFrame S;
+        S.o1 = o1a; S.o2 = o2a;
+        const float w1 = __builtin_fabsf(y1a), w2 = __builtin_fabsf(y2a);
+        L.w[lane + 64] = w2;
+        if (lane < 2) L.cw[lane] = 0;
+        S.hm = __ballot(!(y1a > 0.0f));
+        S.hp = __ballot(!(y2a > 0.0f));
+        wave_fence();
+        build_byte_luts<8>(L.lut, &L.w[64], lane);
+        S.d0 = wave_xor64(((S.hm >> lane) & 1) ? Pa : 0ull) ^ S.hp;
+        wave_fence();
+        float best; int bestt; u64 bestD, bestE;
+        search2r_device(LL, S, Pa, w1, dir, base2, lane, best, bestt, bestD, bestE);
+        search_finish(L, S, bestE, bestD, f0, lane, cw_out);
+        if (lane == 0) {
+            if (metric_out) metric_out[f0] = best;
+            if (best_out) best_out[f0] = bestt;
+            if (ntep_out) ntep_out[f0] = 2081;
+        }
+        // ---- rotate the pipeline
+        f0 = f1; f1 = f2; f2 = f3;
+        o1a = o1b; o2a = o2b; Pa = Pb; srca = srcb; y1a = y1b; y2a = y2b;
+        o1b = o1c; o2b = o2c; Pb = Pc; srcb = srcc;
+    }
+    if (lane == 0) {   // every wavefront has drawn its last ticket before it counts itself out
+        if (atomicAdd(&tickets[1], 1) == (int)gridDim.x - 1) {
+            __hip_atomic_store(&tickets[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&tickets[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // FS-OSD (fs_osd, FS_OSD/fs_testing.py:129-161): order-by-order scan in the order of
 // generate_sequential_teps (:32-49) with two Hamming-distance rules (one_tep_compare :51-64):
 //   HD < tau_e            -> stop everything (the candidate is appended to optimal_list, :143-146)
@@ -549,7 +716,7 @@ void osd_ctx_release(ldpc_ctx *ctx)
     (void)hipFree(ctx->d_tep);
     if (OsdState *st = state(ctx)) {
         for (auto &kv : st->ws) {
-            (void)hipFree(kv.second.d_perm); (void)hipFree(kv.second.d_parity);
+            (void)hipFree(kv.second.d_perm); (void)hipFree(kv.second.d_parity); (void)hipFree(kv.second.d_tickets);
             (void)hipFree(kv.second.d_pb_ctl); (void)hipFree(kv.second.d_pb_list); (void)hipFree(kv.second.d_pb_spill);
             (void)hipFree(kv.second.d_pb_cache); (void)hipFree(kv.second.d_pb_binned); (void)hipFree(kv.second.d_pb_carry);
         }
@@ -576,6 +743,13 @@ static int stream_ws(ldpc_ctx *ctx, hipStream_t s, int64_t frames, StreamWs **ou
     OsdState *st = state(ctx);
     std::lock_guard<std::mutex> lock(st->mu);
     StreamWs &w = st->ws[s];
+    if (!w.d_tickets) {   // ticket counters of the persistent kernels: zero once, the kernels leave them at zero
+        if (stream_capturing(s))
+            return fail(LDPC_E_NOMEM, "first OSD call on a stream allocates its workspace: run one call (or ldpc_osd_reserve_stream) "
+                        "on the stream before capturing");
+        if (hipMalloc((void **)&w.d_tickets, sizeof(int) * 16) != hipSuccess || hipMemset(w.d_tickets, 0, sizeof(int) * 16) != hipSuccess)
+            return fail(LDPC_E_NOMEM, "OSD ticket counters could not be allocated");
+    }
     if (frames > 0 && frames < st->reserve_frames) frames = st->reserve_frames;
     if (frames > w.cap) {
         if (stream_capturing(s))
@@ -679,6 +853,14 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
         for (int w = 0; w < 4; ++w) { fp.cls_off[w] = st->fs_off[w]; fp.cls_cnt[w] = st->fs_cnt[w]; }
         hipLaunchKernelGGL(osd_fs_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
                            d_perm, d_parity, st->d_tep_fs, fp, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
+                           d_ntep);
+    } else if (p->order == 2 && !(p->reserved & 1) && ctx->dpp_wave_rol_dir != 0 && !(p->reserved & 8)) {
+        // persistent grid: 3.5 wavefronts per SIMD fit (11 KiB of LDS each) on 256 CUs
+        const long long grid = (long long)ctx->cu_count * 14;
+        StreamWs *w;
+        if (int rc = stream_ws(ctx, s, 0, &w)) return rc;
+        hipLaunchKernelGGL(osd_search2r_kernel, dim3((unsigned)(F < grid ? F : grid)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
+                           d_perm, d_parity, ctx->dpp_wave_rol_dir, st->d_base2, w->d_tickets, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
                            d_ntep);
     } else if (p->order == 2 && !(p->reserved & 1)) {
         hipLaunchKernelGGL(osd_search2_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,

@@ -50,11 +50,10 @@ __global__ __launch_bounds__(256) void eval_counts_kernel(const unsigned long lo
 // context cannot disturb each other).  The flags are cut into at most kMaxSeg contiguous segments, one
 // per block.  A block first counts the set flags BEFORE its segment itself -- 16 flags per load, the flag
 // array is L2-resident (1 B per frame: the last of 64 blocks re-reads 126 KiB at B = 131 072) -- and then
-// scans its own segment 2048 flags at a time, scattering ascending frame numbers.  The redundant prefix
+// scans its own segment 2048 or 8192 flags at a time, scattering ascending frame numbers.  The redundant prefix
 // reads grow with B / 2 per block, i.e. stay ~1 % of the NMS time of the same batch at any B.
 // The block that owns the last segment writes the total.
 // ---------------------------------------------------------------------------------------
-constexpr int kChunk = 2048;   // flags per block and step: 256 threads x 8
 constexpr int kMaxSeg = 256;   // segments (= blocks) per launch
 
 __device__ __forceinline__ int nonzero_bytes(unsigned long long v)
@@ -63,101 +62,147 @@ __device__ __forceinline__ int nonzero_bytes(unsigned long long v)
     return __popcll((((v & k7) + k7) | v) & ~k7);
 }
 
-__device__ __forceinline__ unsigned flags8(const unsigned char *flag, long long base, long long B, bool aligned)
+// FPT consecutive flags of one thread as a bit mask
+template <int FPT>
+__device__ __forceinline__ unsigned flags_of(const unsigned char *flag, long long base, long long B, bool aligned)
 {
     unsigned bits = 0;
-    if (aligned && base + 8 <= B) {
+    if (FPT == 8 && aligned && base + 8 <= B) {
         unsigned long long v = *reinterpret_cast<const unsigned long long *>(flag + base);
 #pragma unroll
         for (int i = 0; i < 8; ++i) bits |= (unsigned)(((v >> (8 * i)) & 0xFF) != 0) << i;
     } else {
-        for (int i = 0; i < 8 && base + i < B; ++i) bits |= (unsigned)(flag[base + i] != 0) << i;
+#pragma unroll
+        for (int i = 0; i < FPT; ++i) if (base + i < B) bits |= (unsigned)(flag[base + i] != 0) << i;
     }
     return bits;
 }
 
-__device__ __forceinline__ int block_sum_256(int v, int *wsum /*[4] shared*/)
+constexpr int kCompactThreads = 1024, kCompactWaves = kCompactThreads / 64;
+
+__device__ __forceinline__ int block_sum(int v, int *wsum /*[kCompactWaves] shared*/)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     __syncthreads();                         // wsum may still be read from an earlier use
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
     __syncthreads();
-    return wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < kCompactWaves; ++w) t += wsum[w];
+    return t;
 }
 
 // EVAL: the get_eval counters of the same frames ride along (ldpc_pipeline_run: the flags are the
-// syndrome flags either way), so the pipeline needs neither eval_counts_kernel nor a second pass
-template <bool EVAL>
-__global__ __launch_bounds__(256) void compact_kernel(const unsigned char *__restrict__ flag, long long B, long long seg,
-                                                      int *__restrict__ index, int *__restrict__ count,
-                                                      const unsigned long long *__restrict__ hard,
-                                                      const unsigned long long *__restrict__ label, int words,
-                                                      unsigned long long *__restrict__ counts)
+// syndrome flags either way), so the pipeline needs neither eval_counts_kernel nor a second pass.
+// 1024 threads per block: the prefix count of the LAST block is a chain of (flags before it) / 16 KiB dependent
+// trips of ~0.4 us each (the flags were written by other XCDs: L2 misses) -- 8 trips at B = 131 072.
+// FPT flags per thread and step: 2 for batches up to 524 288 frames (2048 flags per block), 8 beyond.
+template <bool EVAL, int FPT>
+__global__ __launch_bounds__(kCompactThreads) void compact_kernel(const unsigned char *__restrict__ flag, long long B, long long seg,
+                                                                  int *__restrict__ index, int *__restrict__ count,
+                                                                  const unsigned long long *__restrict__ hard,
+                                                                  const unsigned long long *__restrict__ label, int words,
+                                                                  unsigned long long *__restrict__ counts)
 {
-    __shared__ int wsum[4];
-    __shared__ unsigned long long epart[4][4];
+    constexpr int NT = kCompactThreads, kStep = NT * FPT;
+    __shared__ int wsum[kCompactWaves];
+    __shared__ unsigned long long epart[kCompactWaves][4];
     const long long lo = (long long)blockIdx.x * seg;
     const long long hi = lo + seg < B ? lo + seg : B;
     const bool al16 = (reinterpret_cast<unsigned long long>(flag) & 15) == 0;
-    // ---- set flags before this segment (lo is a multiple of kChunk)
+    // ---- set flags before this segment (lo is a multiple of 16): independent loads, four in flight per thread
     int acc = 0;
     if (al16) {
-        for (long long i = (long long)threadIdx.x * 16; i < lo; i += 256 * 16) {
+        long long i = (long long)threadIdx.x * 16;
+        for (; i + 3LL * NT * 16 < lo; i += 4LL * NT * 16) {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(flag + i), v1 = *reinterpret_cast<const uint4 *>(flag + i + NT * 16LL);
+            const uint4 v2 = *reinterpret_cast<const uint4 *>(flag + i + 2LL * NT * 16), v3 = *reinterpret_cast<const uint4 *>(flag + i + 3LL * NT * 16);
+            acc += nonzero_bytes(((unsigned long long)v0.y << 32) | v0.x) + nonzero_bytes(((unsigned long long)v0.w << 32) | v0.z);
+            acc += nonzero_bytes(((unsigned long long)v1.y << 32) | v1.x) + nonzero_bytes(((unsigned long long)v1.w << 32) | v1.z);
+            acc += nonzero_bytes(((unsigned long long)v2.y << 32) | v2.x) + nonzero_bytes(((unsigned long long)v2.w << 32) | v2.z);
+            acc += nonzero_bytes(((unsigned long long)v3.y << 32) | v3.x) + nonzero_bytes(((unsigned long long)v3.w << 32) | v3.z);
+        }
+        for (; i < lo; i += NT * 16LL) {
             const uint4 v = *reinterpret_cast<const uint4 *>(flag + i);
             acc += nonzero_bytes(((unsigned long long)v.y << 32) | v.x) + nonzero_bytes(((unsigned long long)v.w << 32) | v.z);
         }
     } else {
-        for (long long i = threadIdx.x; i < lo; i += 256) acc += flag[i] != 0;
+        for (long long i = threadIdx.x; i < lo; i += NT) acc += flag[i] != 0;
     }
-    int base = block_sum_256(acc, wsum);
+    int base = block_sum(acc, wsum);
     // ---- own segment
     unsigned long long ferr = 0, berr = 0, und = 0, cnt = 0;
-    const int lane = threadIdx.x & 63;
-    for (long long c0 = lo; c0 < hi; c0 += kChunk) {
-        const long long fb = c0 + threadIdx.x * 8;
-        const unsigned bits = fb < hi ? flags8(flag, fb, hi, al16) : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long c0 = lo; c0 < hi; c0 += kStep) {
+        const long long fb = c0 + threadIdx.x * FPT;
+        const unsigned bits = fb < hi ? flags_of<FPT>(flag, fb, hi, al16) : 0;
         const int mine = __popc(bits);
-        if constexpr (EVAL) {
-            for (int i = 0; i < 8 && fb + i < hi; ++i) {
-                const long long f = fb + i;
-                int e = 0;
-                for (int w = 0; w < words; ++w) e += __popcll(hard[f * words + w] ^ label[f * words + w]);
-                cnt += 1; berr += e; ferr += e != 0; und += (!((bits >> i) & 1) && e != 0);
+        if constexpr (EVAL) {   // frame c0 + q NT + thread: coalesced 16-byte loads of the hard words and labels
+#pragma unroll
+            for (int q = 0; q < FPT; ++q) {
+                const long long f = c0 + q * NT + threadIdx.x;
+                if (f < hi) {
+                    int e = 0;
+                    for (int w = 0; w < words; ++w) e += __popcll(hard[f * words + w] ^ label[f * words + w]);
+                    cnt += 1; berr += e; ferr += e != 0; und += (flag[f] == 0 && e != 0);
+                }
             }
         }
-        int incl = mine;   // exclusive scan over the 256 threads: in-wave inclusive scan, then wave offsets
+        int incl = mine;   // exclusive scan over the threads: in-wave inclusive scan, then wave offsets
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off, 64);
             if (lane >= off) incl += t;
         }
         __syncthreads();
-        if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kCompactWaves; ++w) { woff += w < wave ? wsum[w] : 0; tot += wsum[w]; }
         int pos = base + woff + incl - mine;
-        for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int i = 0; i < FPT; ++i)
             if ((bits >> i) & 1) index[pos++] = (int)(fb + i);
-        base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        base += tot;
     }
     if (hi == B && threadIdx.x == 0) *count = base;
     if constexpr (EVAL) {   // counts[] = {frames, frame_err, bit_err, undetected, synd_fail}
         cnt = wave_sum(cnt); ferr = wave_sum(ferr); berr = wave_sum(berr); und = wave_sum(und);
-        if (lane == 0) { const int w = threadIdx.x >> 6; epart[w][0] = cnt; epart[w][1] = ferr; epart[w][2] = berr; epart[w][3] = und; }
-        const int before = block_sum_256(acc, wsum);   // (also the barrier that publishes epart)
-        if (threadIdx.x < 4) atomicAdd(&counts[threadIdx.x], epart[0][threadIdx.x] + epart[1][threadIdx.x] + epart[2][threadIdx.x] + epart[3][threadIdx.x]);
+        if (lane == 0) { epart[wave][0] = cnt; epart[wave][1] = ferr; epart[wave][2] = berr; epart[wave][3] = und; }
+        const int before = block_sum(acc, wsum);   // (also the barrier that publishes epart)
+        if (threadIdx.x < 4) {
+            unsigned long long t = 0;
+#pragma unroll
+            for (int w = 0; w < kCompactWaves; ++w) t += epart[w][threadIdx.x];
+            atomicAdd(&counts[threadIdx.x], t);
+        }
         if (threadIdx.x == 4) atomicAdd(&counts[4], (unsigned long long)(base - before));
     }
 }
 
-static void compact_geometry(int64_t B, unsigned *blocks, long long *seg)
+static void compact_geometry(int64_t B, int fpt, unsigned *blocks, long long *seg)
 {
-    const int64_t chunks = (B + kChunk - 1) / kChunk;
-    const int64_t per = (chunks + kMaxSeg - 1) / kMaxSeg;   // chunks per segment
-    *seg = (long long)per * kChunk;
+    const int64_t step = (int64_t)kCompactThreads * fpt;
+    const int64_t chunks = (B + step - 1) / step;
+    const int64_t per = (chunks + kMaxSeg - 1) / kMaxSeg;   // steps per segment
+    *seg = (long long)per * step;
     *blocks = (unsigned)((B + *seg - 1) / *seg);
+}
+
+template <bool EVAL>
+static void launch_compact(const uint8_t *d_flag, int64_t B, int32_t *d_index, int32_t *d_count, const unsigned long long *hard,
+                           const unsigned long long *label, int words, unsigned long long *counts, hipStream_t st)
+{
+    unsigned blocks; long long seg;
+    if (B <= (int64_t)kMaxSeg * kCompactThreads * 2) {
+        compact_geometry(B, 2, &blocks, &seg);
+        hipLaunchKernelGGL((compact_kernel<EVAL, 2>), dim3(blocks), dim3(kCompactThreads), 0, st, d_flag, (long long)B, seg, d_index, d_count, hard, label, words, counts);
+    } else {
+        compact_geometry(B, 8, &blocks, &seg);
+        hipLaunchKernelGGL((compact_kernel<EVAL, 8>), dim3(blocks), dim3(kCompactThreads), 0, st, d_flag, (long long)B, seg, d_index, d_count, hard, label, words, counts);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -223,11 +268,7 @@ int ldpc_compact(ldpc_ctx *ctx, const uint8_t *d_flag, int64_t B, int32_t *d_ind
         return fail(LDPC_E_ARG, "ldpc_compact: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) { LDPC_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return LDPC_OK; }
-    unsigned blocks; long long seg;
-    compact_geometry(B, &blocks, &seg);
-    hipLaunchKernelGGL(compact_kernel<false>, dim3(blocks), dim3(256), 0, st, d_flag, (long long)B, seg, d_index, d_count,
-                       (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, 0,
-                       (unsigned long long *)nullptr);
+    launch_compact<false>(d_flag, B, d_index, d_count, nullptr, nullptr, 0, nullptr, st);
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;
 }
@@ -242,12 +283,9 @@ int eval_and_compact(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_la
 {
     if (!ctx || !d_hard || !d_label || !d_fail || !d_counts || !d_index || !d_count || B <= 0 || B > 0x7FFFFFFFLL)
         return fail(LDPC_E_ARG, "eval_and_compact: bad arguments");
-    unsigned blocks; long long seg;
-    compact_geometry(B, &blocks, &seg);
-    hipLaunchKernelGGL(compact_kernel<true>, dim3(blocks), dim3(256), 0, st, d_fail, (long long)B, seg, d_index, d_count,
-                       reinterpret_cast<const unsigned long long *>(d_hard),
-                       reinterpret_cast<const unsigned long long *>(d_label), (ctx->code.n + 63) / 64,
-                       reinterpret_cast<unsigned long long *>(d_counts));
+    launch_compact<true>(d_fail, B, d_index, d_count, reinterpret_cast<const unsigned long long *>(d_hard),
+                         reinterpret_cast<const unsigned long long *>(d_label), (ctx->code.n + 63) / 64,
+                         reinterpret_cast<unsigned long long *>(d_counts), st);
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;
 }

@@ -185,11 +185,13 @@ def test_order2_register_kernel_equals_table_scan_with_ties(dec):
     y[200:300] = np.sign(y[200:300])                                                   # all |y| = 1
     y[300:320] = np.where(rng.random((20, 128)) < 0.5, 1.0, -1.0).astype(np.float32) * 0.25
     yd = to_dev(y, dec)
-    a = dec.osd_decode(yd, 2)
+    a = dec.osd_decode(yd, 2)                                                # rotation-paired persistent kernel
     b = dec.osd_decode(yd, 2, params=dec.osd_params(2, table_scan=True))
+    c = dec.osd_decode(yd, 2, params=dec.osd_params(2, readlane_scan=True))  # first register-resident kernel
     torch.cuda.synchronize()
     for k in ("cw", "metric", "best", "ntep"):
         assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a[k], c[k]), k
     ref = c_oracle.conv_osd(dec.code.G, y, cw, 2)
     assert np.array_equal(a["best"].cpu().numpy(), ref["best"])
     assert np.array_equal(words_np(a["cw"]), pack_np(ref["codeword"]))
