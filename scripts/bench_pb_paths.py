@@ -59,7 +59,7 @@ def main():
     yf = y[index[:nf].long()].contiguous()
     perm, parity, _ = dec.osd_front(yf)
     out = []
-    for name, F, snr, path in [("typical staged", nf, 2.5, None), ("typical all-through-workgroup-kernel", nf, 2.5, "block"),
+    for name, F, snr, path in [] if os.environ.get("LDPC_S2_GRID_MULT") else [("typical staged", nf, 2.5, None), ("typical all-through-workgroup-kernel", nf, 2.5, "block"),
                                ("typical 8192 workgroup-kernel", 8192, 2.5, "block"), ("typical 1024 workgroup-kernel", 1024, 2.5, "block"),
                                ("full scans x256", 256, -5.0, "block"), ("full scans x1024", 1024, -5.0, "block"),
                                ("full scans x4096", 4096, -5.0, "block"), ("full scans x64 list replay", 64, -5.0, "replay")]:

@@ -436,21 +436,18 @@ __device__ __forceinline__ void search2r_device(Search2Lds &LL, const SearchFram
     best_out = best; rank_out = bestt; D_out = bestD; E_out = bestE;
 }
 
-// frames are handed out by a ticket counter (scan times differ with the number of survivors: with a static split
-// the wavefronts were alive for only 63 % of the launch); the last wavefront to leave resets the two counters, so
-// no memset precedes the launch.  tickets[0] = next frame, tickets[1] = wavefronts that have left.
-__device__ __forceinline__ long long search2r_ticket(int *__restrict__ tickets, int lane)
-{
-    int t = 0;
-    if (lane == 0) t = atomicAdd(&tickets[0], 1);
-    return __builtin_amdgcn_readfirstlane(t);
-}
-
+// Frame assignment is static (frame = block + k grid).  Dynamic hand-out was measured and dropped: a device-scope
+// ticket word saturates at ~88 fetch-adds per us (MI355X_MICROARCH.md, "dequeue") and a returning atomic takes
+// microseconds under load -- every frame through ONE ticket word: 551 us; through 16 words on their own 128-byte
+// lines, result awaited at once: 213 us; the last 40 % of the frames through 16 words, drawn a whole scan before
+// they are looked at: 129 us; static: 102 us (the wavefronts are then alive for ~63 % of the launch: the scan time
+// varies with the number of survivors) -- so the balance comes from the hardware dispatcher instead: the grid is 6x
+// the resident wavefronts (see the launcher).
 __global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                           const int *__restrict__ count, long long F,
                                                           const unsigned char *__restrict__ perm_in,
                                                           const u64 *__restrict__ parity_in, int dir,
-                                                          const int *__restrict__ base2, int *__restrict__ tickets,
+                                                          const int *__restrict__ base2,
                                                           u64 *__restrict__ cw_out, float *__restrict__ metric_out,
                                                           int *__restrict__ best_out, int *__restrict__ ntep_out)
 {
@@ -460,7 +457,8 @@ __global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restric
     long long nframes = F;
     if (count) { const long long c = *count; nframes = c < F ? c : F; }
     // software pipeline over the frames of this workgroup: (o, P) two frames ahead, y one frame ahead
-    long long f0 = search2r_ticket(tickets, lane), f1 = search2r_ticket(tickets, lane), f2 = search2r_ticket(tickets, lane);
+    const long long G = gridDim.x;
+    long long f0 = blockIdx.x, f1 = f0 + G, f2 = f1 + G;
     int o1a = 0, o2a = 0, o1b = 0, o2b = 0;
     u64 Pa = 0, Pb = 0;
     long long srca = 0, srcb = 0;
@@ -475,8 +473,7 @@ __global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restric
     }
     if (f0 < nframes) { y1a = y[srca * 128 + o1a]; y2a = y[srca * 128 + o2a]; }
     while (f0 < nframes) {
-        // issue the loads of the frames ahead (they are consumed one / two trips later) and draw the next ticket
-        const long long f3 = search2r_ticket(tickets, lane);
+        // issue the loads of the frames ahead (they are consumed one / two trips later)
         float y1b = 0.0f, y2b = 0.0f;
         if (f1 < nframes) { y1b = y[srcb * 128 + o1b]; y2b = y[srcb * 128 + o2b]; }
         int o1c = 0, o2c = 0;
@@ -507,15 +504,9 @@ __global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restric
             if (ntep_out) ntep_out[f0] = 2081;
         }
         // ---- rotate the pipeline
-        f0 = f1; f1 = f2; f2 = f3;
+        f0 = f1; f1 = f2; f2 += G;
         o1a = o1b; o2a = o2b; Pa = Pb; srca = srcb; y1a = y1b; y2a = y2b;
         o1b = o1c; o2b = o2c; Pb = Pc; srcb = srcc;
-    }
-    if (lane == 0) {   // every wavefront has drawn its last ticket before it counts itself out
-        if (atomicAdd(&tickets[1], 1) == (int)gridDim.x - 1) {
-            __hip_atomic_store(&tickets[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&tickets[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
@@ -716,7 +707,7 @@ void osd_ctx_release(ldpc_ctx *ctx)
     (void)hipFree(ctx->d_tep);
     if (OsdState *st = state(ctx)) {
         for (auto &kv : st->ws) {
-            (void)hipFree(kv.second.d_perm); (void)hipFree(kv.second.d_parity); (void)hipFree(kv.second.d_tickets);
+            (void)hipFree(kv.second.d_perm); (void)hipFree(kv.second.d_parity);
             (void)hipFree(kv.second.d_pb_ctl); (void)hipFree(kv.second.d_pb_list); (void)hipFree(kv.second.d_pb_spill);
             (void)hipFree(kv.second.d_pb_cache); (void)hipFree(kv.second.d_pb_binned); (void)hipFree(kv.second.d_pb_carry);
         }
@@ -743,13 +734,6 @@ static int stream_ws(ldpc_ctx *ctx, hipStream_t s, int64_t frames, StreamWs **ou
     OsdState *st = state(ctx);
     std::lock_guard<std::mutex> lock(st->mu);
     StreamWs &w = st->ws[s];
-    if (!w.d_tickets) {   // ticket counters of the persistent kernels: zero once, the kernels leave them at zero
-        if (stream_capturing(s))
-            return fail(LDPC_E_NOMEM, "first OSD call on a stream allocates its workspace: run one call (or ldpc_osd_reserve_stream) "
-                        "on the stream before capturing");
-        if (hipMalloc((void **)&w.d_tickets, sizeof(int) * 16) != hipSuccess || hipMemset(w.d_tickets, 0, sizeof(int) * 16) != hipSuccess)
-            return fail(LDPC_E_NOMEM, "OSD ticket counters could not be allocated");
-    }
     if (frames > 0 && frames < st->reserve_frames) frames = st->reserve_frames;
     if (frames > w.cap) {
         if (stream_capturing(s))
@@ -855,13 +839,12 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
                            d_perm, d_parity, st->d_tep_fs, fp, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
                            d_ntep);
     } else if (p->order == 2 && !(p->reserved & 1) && ctx->dpp_wave_rol_dir != 0 && !(p->reserved & 8)) {
-        // persistent grid: 3.5 wavefronts per SIMD fit (11 KiB of LDS each) on 256 CUs
-        const long long grid = (long long)ctx->cu_count * 14;
-        StreamWs *w;
-        if (int rc = stream_ws(ctx, s, 0, &w)) return rc;
+        // 3.5 wavefronts per SIMD are resident (11 KiB of LDS each); the grid is 6x that, ~1.5 frames per workgroup at the
+        // headline size: the dispatcher then evens out the different scan times, and the prefetch still covers the second
+        // frame (measured, 33 487 frames: 1x 119 us, 2x 117, 3x 108, 4x 107, 6x 100, 9x 102 per call incl. events)
+        const long long grid = (long long)ctx->cu_count * 14 * 6;
         hipLaunchKernelGGL(osd_search2r_kernel, dim3((unsigned)(F < grid ? F : grid)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
-                           d_perm, d_parity, ctx->dpp_wave_rol_dir, st->d_base2, w->d_tickets, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
-                           d_ntep);
+                           d_perm, d_parity, ctx->dpp_wave_rol_dir, st->d_base2, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
     } else if (p->order == 2 && !(p->reserved & 1)) {
         hipLaunchKernelGGL(osd_search2_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
                            d_perm, d_parity, st->d_base2, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);

@@ -12,7 +12,6 @@ struct StreamWs {
     unsigned char *d_perm = nullptr;  // ldpc_osd_decode: front-end results [cap][128]
     u64 *d_parity = nullptr;          //                                    [cap][64]
     int64_t cap = 0;
-    int *d_tickets = nullptr;         // frame tickets of the persistent scan kernels (self-resetting, 16 ints)
     int *d_pb_ctl = nullptr;          // PB-OSD: frame tickets and list lengths (kPbCtlInts ints, zeroed per call)
     int *d_pb_list = nullptr;         // PB-OSD: [3][pb_cap] frames handed on: list A (stage A), B (list replay), C (stage B)
     void *d_pb_carry = nullptr;       // PB-OSD: [pb_cap] search state of the frames on list C
