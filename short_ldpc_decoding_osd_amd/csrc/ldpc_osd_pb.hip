@@ -177,15 +177,23 @@ __device__ __forceinline__ bool pb_not_promising(float rs, float best, const PbF
     return (double)bs < F.p_t_pro;
 }
 
-// success rule (acquire_p_e_suc :423-436) for a candidate that became the best: true = stop
-__device__ __forceinline__ bool pb_success(u64 D, float w1, const float *q, const PbFrame &F)
+// success rule (acquire_p_e_suc :423-436) for a candidate that became the best: true = stop.
+// tq[p] = {2 (1 - q_p), 2 q_p} of parity position p (pb_success_terms): the factor of the sequential product is picked
+// by the discrepancy bit -- a broadcast LDS read and a select per position instead of recomputing both terms.
+__device__ __forceinline__ void pb_success_terms(const float *q, float2 *tq, int lane)
+{
+    const float qp = q[64 + lane];
+    tq[lane] = make_float2(2.0f * (1.0f - qp), 2.0f * qp);
+}
+
+__device__ __forceinline__ bool pb_success(u64 D, float w1, const float2 *tq, const PbFrame &F)
 {
     const float ratio = (1.0f - w1) / w1;
     float prod = 1.0f;
-#pragma unroll 4
+#pragma unroll 8
     for (int p = 0; p < 64; ++p) {
-        const float qp = q[64 + p];
-        prod = prod * (((D >> p) & 1) ? 2.0f * qp : 2.0f * (1.0f - qp));
+        const float2 t = tq[p];
+        prod = prod * (((D >> p) & 1) ? t.y : t.x);
     }
     const float p_suc = 1.0f / (1.0f + ratio / prod);
     return (double)p_suc > F.p_t_suc;
@@ -259,6 +267,14 @@ __device__ __forceinline__ void pb_apply(const SearchLds &L, const PbTep &t, u64
 struct PbOut {
     u64 *cw; float *metric; int *best, *ntep, *aux;
 };
+
+// per-frame quantities of pb_frame_setup, written by the stage that computed them first (pb_singles_kernel) for the
+// frames it hands on, so that the workgroup kernels load ~1 KiB instead of repeating two 64-step sequential loops
+struct PbPrep {
+    double cdfA[65];
+    float q[128];
+    PbFrame fr;
+};
 __device__ __forceinline__ void pb_write(SearchLds &L, const SearchFrame &S, const PbOut &O, long long f, int lane, u64 bestE,
                                          u64 bestD, float best, int bestidx, int ntep, int cmp, int suc1, int suc2, int stop)
 {
@@ -294,6 +310,7 @@ struct PbSinglesLds {
     SearchLds s;
     double cdfA[65], cdfH[65];
     float q[128];
+    float2 tq[64];
 };
 
 __global__ __launch_bounds__(256) void pb_singles_kernel(const float *__restrict__ y, const int *__restrict__ index,
@@ -302,7 +319,7 @@ __global__ __launch_bounds__(256) void pb_singles_kernel(const float *__restrict
                                                          const u64 *__restrict__ parity_in, PbParams P, int mode,
                                                          const double *__restrict__ cdf_half, const double *__restrict__ coef,
                                                          int *__restrict__ ctl, int *__restrict__ listA, int *__restrict__ listB,
-                                                         PbOut O)
+                                                         PbPrep *__restrict__ prep, PbOut O)
 {
     __shared__ PbSinglesLds lds[4];
     const int lane = threadIdx.x & 63;
@@ -323,6 +340,8 @@ __global__ __launch_bounds__(256) void pb_singles_kernel(const float *__restrict
         const long long src = index ? index[f] : f;
         const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
         const PbFrame Fr = pb_frame_setup(L, W.q, W.cdfA, coef, P.c4, P.order, P.nmax, lane);
+        pb_success_terms(W.q, W.tq, lane);
+        wave_fence();
         const float best0 = tep_cost(L, 0.0f, S.d0);
         // lane l <-> TEP {63 - l}, visit index l; valid while its weight is below the smallest weight-2 sum
         const int p = 63 - lane;
@@ -340,10 +359,13 @@ __global__ __launch_bounds__(256) void pb_singles_kernel(const float *__restrict
         const bool stop1 = valid && pb_not_promising(rs, before, Fr, P.c4, W.cdfA, W.cdfH, w1);
         const bool newbest = valid && cost < before;
         bool stop2 = false;
-        if (newbest) stop2 = pb_success(D, w1, W.q, Fr);
+        if (newbest) stop2 = pb_success(D, w1, W.tq, Fr);
         const u64 sm = __ballot(stop1 || stop2);
-        if (sm == 0 && P.order > 1) {   // no rule fired on the head: the block kernel takes the frame
-            if (lane == 0) listA[atomicAdd(&ctl[1], 1)] = (int)f;
+        if (sm == 0 && P.order > 1) {   // no rule fired on the head: the block kernel takes the frame (and what was computed for it)
+            PbPrep &R = prep[f];
+            R.q[lane] = W.q[lane]; R.q[lane + 64] = W.q[lane + 64];
+            R.cdfA[lane] = W.cdfA[lane];
+            if (lane == 0) { R.cdfA[64] = W.cdfA[64]; R.fr = Fr; listA[atomicAdd(&ctl[1], 1)] = (int)f; }
             continue;
         }
         const int ls = sm ? __builtin_ctzll(sm) : 63;                 // (order 1 without a stop: all 64 TEPs visited)
@@ -377,8 +399,10 @@ struct __attribute__((aligned(16))) PbBlockLds {
     SearchLds s;
     double cdfA[65], cdfH[65];
     float q[128];
-    u64 keys[CAP];          // (sum bits << 32) | table id
-    float cost[CAP];
+    float2 tq[64];
+    u64 gath[CAP];          // the chunk as gathered: (sum bits << 32) | table id; after the sort: the costs (float[CAP])
+    u64 keys[CAP];          // the chunk in visit order
+    int bucket[CAP];        // bucket sort: counts, then cursors
     int hist[kPbBins];
     int binoff[kPbBins + 1];
     float red_f[2][NT / 64];
@@ -389,8 +413,8 @@ struct __attribute__((aligned(16))) PbBlockLds {
     int j, nlive, cmp, suc1, suc2, bestidx;
     u64 bestD, bestE, d0;
     // per-chunk scratch
-    int nkeys, bstar, degenerate, gstop, reason, ones, nev, nnb, lnb, ticket;
-    unsigned long long prof[16], prof_last;   // diagnostic build only (LDPC_PB_PROFILE)
+    int nkeys, bstar, degenerate, fallback, gstop, reason, ones, nev, nnb, lnb, ticket;
+    unsigned long long prof[24], prof_last;   // diagnostic build only (LDPC_PB_PROFILE)
 };
 
 // In-kernel stamps of the diagnostic instantiation (PROF = true, launched only when LDPC_PB_PROFILE is set): thread 0
@@ -487,34 +511,94 @@ __device__ int pb_process_chunk(PbBlockLds<NT, CAP> &B, const uchar4 *__restrict
     constexpr int W = NT / 64;
     SearchLds &L = B.s;
     const int lane = tid & 63, wave = tid >> 6;
-    int npow = 2;
-    while (npow < n) npow <<= 1;
-    for (int i = n + tid; i < npow; i += NT) B.keys[i] = ~0ull;
-    __syncthreads();
-    // ---- bitonic sort, ascending
-    for (int k = 2; k <= npow; k <<= 1)
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int i = tid; i < (npow >> 1); i += NT) {
-                const int a = ((i & ~(jj - 1)) << 1) | (i & (jj - 1)), b = a | jj;
-                const u64 x = B.keys[a], yv = B.keys[b];
-                if ((x > yv) == ((a & k) == 0)) { B.keys[a] = yv; B.keys[b] = x; }
+    u64 *const K = B.gath;                              // the chunk in visit order ends up where it was gathered
+    // ---- bucket sort.  CAP buckets over [min, max] of the chunk's sums hold ~1 key each (<= ~14 near the dense upper
+    // end): counts -> offsets (scan) -> scatter into B.keys (grouped by bucket) -> every key counts the keys of its own
+    // bucket that sort before it and lands at bucket start + rank in B.gath.  No dependent chains: a bitonic sort of the
+    // same 1024 keys took 55 barrier-separated LDS steps (39 % of the stage-A kernel), an insertion sort inside the
+    // buckets left one thread with ~50 dependent LDS round trips; this is ~8 barriers and independent reads.
+    {
+        int dummy = 0;
+        float mn = __builtin_inff(), mx = -1.0f;
+        for (int i = tid; i < n; i += NT) {
+            const float sv = __uint_as_float((unsigned)(B.gath[i] >> 32));
+            mn = __builtin_fminf(mn, sv); mx = __builtin_fmaxf(mx, sv);
+        }
+        for (int b = tid; b < CAP; b += NT) B.bucket[b] = 0;
+        if (tid == 0) B.fallback = 0;
+        pb_reduce3(B, dummy, mn, mx, lane, wave);
+        PB_STAMP(16);
+        const float scale = mx > mn ? (float)CAP / (mx - mn) : 0.0f;
+        const bool flat = !(scale < 3.0e38f);           // denormally close sums: one bucket
+        for (int i = tid; i < n; i += NT) {
+            const float sv = __uint_as_float((unsigned)(B.gath[i] >> 32));
+            atomicAdd(&B.bucket[flat ? 0 : (int)__builtin_fminf((sv - mn) * scale, (float)(CAP - 1))], 1);
+        }
+        __syncthreads();
+        PB_STAMP(17);
+        constexpr int PERB = CAP / NT;
+        int cnts[PERB], local = 0;
+#pragma unroll
+        for (int q = 0; q < PERB; ++q) { cnts[q] = B.bucket[tid * PERB + q]; local += cnts[q]; if (cnts[q] > 64) B.fallback = 1; }
+        const int incl = wave_incl_add(local, lane);
+        if (lane == 63) B.red_i[0][wave] = incl;
+        __syncthreads();
+        int run = incl - local;
+        for (int w = 0; w < wave; ++w) run += B.red_i[0][w];
+#pragma unroll
+        for (int q = 0; q < PERB; ++q) { B.bucket[tid * PERB + q] = run; run += cnts[q]; }    // start offsets = cursors
+        __syncthreads();
+        PB_STAMP(18);
+        if (!B.fallback) {
+            for (int i = tid; i < n; i += NT) {
+                const u64 key = B.gath[i];
+                const float sv = __uint_as_float((unsigned)(key >> 32));
+                B.keys[atomicAdd(&B.bucket[flat ? 0 : (int)__builtin_fminf((sv - mn) * scale, (float)(CAP - 1))], 1)] = key;
+            }
+            __syncthreads();   // cursors are now the END offsets of the buckets
+            PB_STAMP(19);
+            for (int i = tid; i < n; i += NT) {
+                const u64 key = B.keys[i];
+                const float sv = __uint_as_float((unsigned)(key >> 32));
+                const int b = flat ? 0 : (int)__builtin_fminf((sv - mn) * scale, (float)(CAP - 1));
+                const int end = B.bucket[b], start = b ? B.bucket[b - 1] : 0;
+                int r = 0;
+                for (int jj = start; jj < end; ++jj) r += B.keys[jj] < key;
+                K[start + r] = key;
             }
             __syncthreads();
+            PB_STAMP(20);
+        } else {   // a crowded bucket (massively clustered sums): bitonic sort of the whole chunk in place
+            int npow = 2;
+            while (npow < n) npow <<= 1;
+            for (int i = n + tid; i < npow; i += NT) K[i] = ~0ull;
+            __syncthreads();
+            for (int k = 2; k <= npow; k <<= 1)
+                for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                    for (int i = tid; i < (npow >> 1); i += NT) {
+                        const int a = ((i & ~(jj - 1)) << 1) | (i & (jj - 1)), b = a | jj;
+                        const u64 x = K[a], yv = K[b];
+                        if ((x > yv) == ((a & k) == 0)) { K[a] = yv; K[b] = x; }
+                    }
+                    __syncthreads();
+                }
         }
+        if constexpr (PROF) { if (tid == 0) { B.prof[14] += B.fallback; B.prof[15] += n; } }
+    }
     PB_STAMP(kProfSort);
     // ---- equal sums: list order (pb_visit_less); one thread per run of equal sums
     for (int i = tid; i + 1 < n; i += NT) {
-        const unsigned si = (unsigned)(B.keys[i] >> 32);
-        if ((i == 0 || (unsigned)(B.keys[i - 1] >> 32) != si) && (unsigned)(B.keys[i + 1] >> 32) == si) {
+        const unsigned si = (unsigned)(K[i] >> 32);
+        if ((i == 0 || (unsigned)(K[i - 1] >> 32) != si) && (unsigned)(K[i + 1] >> 32) == si) {
             int g = 2;
-            while (i + g < n && g <= kPbMaxTie && (unsigned)(B.keys[i + g] >> 32) == si) ++g;
+            while (i + g < n && g <= kPbMaxTie && (unsigned)(K[i + g] >> 32) == si) ++g;
             if (g > kPbMaxTie) { B.degenerate = 1; continue; }
             for (int a = 1; a < g; ++a) {
-                const u64 ka = B.keys[i + a];
+                const u64 ka = K[i + a];
                 const PbTep ta = pb_tep(tab, (int)(unsigned)ka);
                 int b = a;
-                while (b > 0 && pb_visit_less(L.w, ta, pb_tep(tab, (int)(unsigned)B.keys[i + b - 1]))) { B.keys[i + b] = B.keys[i + b - 1]; --b; }
-                B.keys[i + b] = ka;
+                while (b > 0 && pb_visit_less(L.w, ta, pb_tep(tab, (int)(unsigned)K[i + b - 1]))) { K[i + b] = K[i + b - 1]; --b; }
+                K[i + b] = ka;
             }
         }
     }
@@ -522,20 +606,31 @@ __device__ int pb_process_chunk(PbBlockLds<NT, CAP> &B, const uchar4 *__restrict
     __syncthreads();
     PB_STAMP(kProfTie);
     if (B.degenerate) return 2;
-    // ---- evaluate: thread t owns the entries [t per, (t+1) per) of the sorted chunk
+    // ---- evaluate: thread t owns the entries [t per, (t+1) per) of the sorted chunk and keeps them in registers
+    // (table entry, discrepancy, cost, frontier growth) from the evaluation to the sequential rules
+    constexpr int PER = CAP / NT;
     const int per = (n + NT - 1) / NT;
     const int i0 = tid * per, i1 = (i0 + per) < n ? (i0 + per) : n;
+    u64 kq[PER], Dq[PER];
+    uchar4 tq4[PER];
+    float cq[PER];
+    int dq[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) kq[q] = (q < per && i0 + q < n) ? K[i0 + q] : 0ull;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) tq4[q] = tab[(unsigned)kq[q] & 0xFFFFu];        // independent loads, issued together
     float tmin = __builtin_inff();
     int tdel = 0;
-    for (int i = i0; i < i1; ++i) {
-        const u64 key = B.keys[i];
-        const PbTep t = pb_tep(tab, (int)(unsigned)key);
-        u64 D, E;
-        pb_apply(L, t, d0, D, E);
-        const float c = tep_cost(L, __uint_as_float((unsigned)(key >> 32)), D);
-        B.cost[i] = c;
-        tmin = __builtin_fminf(tmin, c);
-        tdel += pb_delta(t, P.order);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const bool valid = q < per && i0 + q < n;
+        const PbTep t{tq4[q].x, tq4[q].y, tq4[q].z, tq4[q].w};
+        u64 E;
+        pb_apply(L, t, d0, Dq[q], E);
+        cq[q] = valid ? tep_cost(L, __uint_as_float((unsigned)(kq[q] >> 32)), Dq[q]) : __builtin_inff();
+        dq[q] = valid ? pb_delta(t, P.order) : 0;
+        tmin = __builtin_fminf(tmin, cq[q]);
+        tdel += dq[q];
     }
     // exclusive scans over the threads: min of the costs / sum of the frontier growth before my entries
     const float imin = wave_incl_min(tmin, lane);
@@ -554,37 +649,48 @@ __device__ int pb_process_chunk(PbBlockLds<NT, CAP> &B, const uchar4 *__restrict
     PB_STAMP(kProfEval1);
     // ---- the sequential rules on my entries, assuming no earlier stop
     int ones = 0, nev = 0, nnb = 0, lnb = -1, lstop = 0x7FFFFFFF, lreason = 0;
-    for (int i = i0; i < i1; ++i) {
-        const u64 key = B.keys[i];
-        const float rs = __uint_as_float((unsigned)(key >> 32)), c = B.cost[i];
-        const PbTep t = pb_tep(tab, (int)(unsigned)key);
-        ones += nlb == 1;
-        nlb += pb_delta(t, P.order);
-        float w1;
-        if (pb_not_promising(rs, before, Fr, P.c4, B.cdfA, B.cdfH, w1)) { lstop = i; lreason = 1; break; }
-        ++nev;
-        if (c < before) {
-            before = c; lnb = i; ++nnb;
-            u64 D, E;
-            pb_apply(L, t, d0, D, E);
-            if (pb_success(D, w1, B.q, Fr)) { lstop = i; lreason = 2; break; }
+    float lbest = 0.0f;
+    u64 lD = 0;
+    uchar4 lt = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        if (q < per && i0 + q < n && lstop == 0x7FFFFFFF) {
+            const float rs = __uint_as_float((unsigned)(kq[q] >> 32));
+            ones += nlb == 1;
+            nlb += dq[q];
+            float w1;
+            if (pb_not_promising(rs, before, Fr, P.c4, B.cdfA, B.cdfH, w1)) { lstop = i0 + q; lreason = 1; }
+            else {
+                ++nev;
+                if (cq[q] < before) {
+                    before = cq[q]; lnb = i0 + q; ++nnb; lbest = cq[q]; lD = Dq[q]; lt = tq4[q];
+                    if (pb_success(Dq[q], w1, B.tq, Fr)) { lstop = i0 + q; lreason = 2; }
+                }
+            }
         }
     }
     if (lstop != 0x7FFFFFFF) atomicMin(&B.gstop, lstop);
     __syncthreads();
     PB_STAMP(kProfEval2);
     const int gstop = B.gstop;
-    if (i0 < i1 && i0 <= gstop) {     // my entries lie before (or contain) the first stop: they count
-        atomicAdd(&B.ones, ones); atomicAdd(&B.nev, nev); atomicAdd(&B.nnb, nnb);
-        if (lnb >= 0) atomicMax(&B.lnb, lnb);
-        if (lstop == gstop) B.reason = lreason;
+    {   // my entries count if they lie before (or contain) the first stop; wave sums first, one atomic set per wavefront
+        const bool mine = i0 < i1 && i0 <= gstop;
+        int o = mine ? ones : 0, e = mine ? nev : 0, b = mine ? nnb : 0, l = mine ? lnb : -1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            o += __shfl_xor(o, off, 64); e += __shfl_xor(e, off, 64); b += __shfl_xor(b, off, 64);
+            const int t = __shfl_xor(l, off, 64);
+            l = t > l ? t : l;
+        }
+        if (lane == 0) { atomicAdd(&B.ones, o); atomicAdd(&B.nev, e); atomicAdd(&B.nnb, b); atomicMax(&B.lnb, l); }
+        if (mine && lstop == gstop) B.reason = lreason;
     }
     __syncthreads();
     if (lnb >= 0 && lnb == B.lnb && i0 <= gstop) {   // the last improvement before the stop is mine
-        const PbTep t = pb_tep(tab, (int)(unsigned)B.keys[lnb]);
-        u64 D, E;
-        pb_apply(L, t, d0, D, E);
-        B.best = B.cost[lnb]; B.bestD = D; B.bestE = E; B.bestidx = B.j + lnb + 1;
+        u64 E = 1ull << lt.x;
+        if (lt.w > 1) E |= 1ull << lt.y;
+        if (lt.w > 2) E |= 1ull << lt.z;
+        B.best = lbest; B.bestD = lD; B.bestE = E; B.bestidx = B.j + lnb + 1;
     }
     __syncthreads();
     if (tid == 0) {
@@ -611,24 +717,37 @@ struct PbCarry {
 template <int NT, int CAP>
 __device__ __forceinline__ SearchFrame pb_block_setup(PbBlockLds<NT, CAP> &B, const float *__restrict__ y, long long src, long long f,
                                                       const unsigned char *__restrict__ perm_in, const u64 *__restrict__ parity_in,
-                                                      const PbParams &P, const double *__restrict__ coef, int lane, int wave)
+                                                      const PbParams &P, const double *__restrict__ coef, const PbPrep *__restrict__ prep,
+                                                      int tid)
 {
     SearchLds &L = B.s;
+    const int lane = tid & 63, wave = tid >> 6;
     SearchFrame S{};
-    if (wave == 0) S = search_prepare_regs<false>(L, y, src, perm_in[f * 128 + lane], perm_in[f * 128 + 64 + lane], parity_in[f * 64 + lane], lane);
+    if (wave == 0) {
+        S = search_prepare_regs<false>(L, y, src, perm_in[f * 128 + lane], perm_in[f * 128 + 64 + lane], parity_in[f * 64 + lane], lane);
+        if (lane == 0) { B.d0 = S.d0; B.degenerate = 0; }
+    } else if (prep && wave == 1) {   // meanwhile: what pb_singles_kernel already computed for this frame
+        const PbPrep &R = prep[f];
+        B.q[lane] = R.q[lane]; B.q[lane + 64] = R.q[lane + 64];
+        B.cdfA[lane] = R.cdfA[lane];
+        if (lane == 0) { B.cdfA[64] = R.cdfA[64]; B.fr = R.fr; }
+    }
     __syncthreads();
     for (int b = wave; b < 8; b += NT / 64) build_byte_luts<1>(L.lut + b, &L.w[64 + 8 * b], lane);
     if (wave == 0) {
-        const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, coef, P.c4, P.order, P.nmax, lane);
-        if (lane == 0) { B.fr = Fr; B.d0 = S.d0; B.degenerate = 0; }
+        if (!prep) {
+            const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, coef, P.c4, P.order, P.nmax, lane);
+            if (lane == 0) B.fr = Fr;
+        }
+        pb_success_terms(B.q, B.tq, lane);
     }
     __syncthreads();
     return S;
 }
 
-// Stage A of a frame of list A: the TEPs with sum <= |y'_0| (1e3 of them typically), candidates pruned per weight
-// class, chunks split by a histogram when the bound holds more than CAP TEPs.  A frame on which no rule fires
-// here goes on to list C with its search state (pb_heavy_kernel), massive ties to list B (list replay).
+// Stage A of a frame of list A: the TEPs with sum <= |y'_0| (1e3 of them typically) as ONE chunk, candidates pruned
+// per weight class.  A frame on which no rule fires here -- or whose bound holds more than a chunk -- goes on to
+// list C with its search state (pb_heavy_kernel), massive ties to list B (list replay).
 template <int NT, int CAP, bool PROF>
 __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                       const unsigned char *__restrict__ perm_in,
@@ -636,7 +755,8 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
                                                       const double *__restrict__ cdf_half, const double *__restrict__ coef,
                                                       const uchar4 *__restrict__ tab, int *__restrict__ ctl,
                                                       const int *__restrict__ listA, int *__restrict__ listB,
-                                                      int *__restrict__ listC, PbCarry *__restrict__ carry, PbOut O,
+                                                      int *__restrict__ listC, PbCarry *__restrict__ carry,
+                                                      const PbPrep *__restrict__ prep, PbOut O,
                                                       unsigned long long *__restrict__ prof_out)
 {
     __shared__ PbBlockLds<NT, CAP> B;
@@ -644,7 +764,7 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nlist = ctl[1];
     if (tid < 65) B.cdfH[tid] = cdf_half[tid];
-    if constexpr (PROF) { if (tid < 16) B.prof[tid] = 0; if (tid == 0) B.prof_last = __builtin_amdgcn_s_memtime(); }
+    if constexpr (PROF) { if (tid < 24) B.prof[tid] = 0; if (tid == 0) B.prof_last = __builtin_amdgcn_s_memtime(); }
 
     for (;;) {
         __syncthreads();
@@ -654,7 +774,7 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
         if (tk >= nlist) break;
         const long long f = listA[tk];
         const long long src = index ? index[f] : f;
-        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, coef, lane, wave);
+        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, coef, prep, tid);
         if (tid == 0) {
             B.lo = -1.0f; B.hi_cur = L.w[0];
             B.j = 0; B.nlive = 1; B.cmp = 0; B.suc1 = 0; B.suc2 = 0; B.bestidx = 0;
@@ -663,75 +783,45 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
         }
         __syncthreads();
         PB_STAMP(kProfSetup);
+        unsigned long long fstart = 0, fchunks = 0;
+        if constexpr (PROF) { fstart = __builtin_amdgcn_s_memtime(); fchunks = B.prof[kProfChunks]; }
         const PbFrame Fr = B.fr;
         const u64 d0 = B.d0;
         const float theta = L.w[0];
         int stop = 0, ntep = P.nmax, state = 0;   // state: 0 = searching, 1 = a rule fired, 2 = hand the frame to the list replay
 
-        for (;;) {
-            const float lo = B.lo, hi = B.hi_cur;
-            if (!(lo < theta)) break;
+        {   // ONE pass over the pruned candidates counts the TEPs with sum <= |y'_0| and gathers them on the spot; if they
+            // do not fit one chunk the frame goes to stage B untouched (1024 threads, cached sums, one histogram: the
+            // eight latency-bound passes per chunk this took here made such a frame the 2.4 M-cycle tail of the launch)
             int n1, n2, n3;
-            pb_candidates(L, hi, P.order, lane, n1, n2, n3);
+            pb_candidates(L, theta, P.order, lane, n1, n2, n3);
             const int total = n1 + n2 + n3;
-            int cnt = 0;
-            float mn = __builtin_inff(), mx = -1.0f;
-            for (int i = tid; i < total; i += NT) {
-                int id; float s;
-                pb_cand(tab, L.w, i, n1, n2, id, s);
-                if (s > lo && s <= hi) { ++cnt; mn = __builtin_fminf(mn, s); mx = __builtin_fmaxf(mx, s); }
-            }
-            pb_reduce3(B, cnt, mn, mx, lane, wave);
-            PB_STAMP(kProfPassA);
-            if (cnt == 0) {   // nothing (left) below the bound: next range
-                if (tid == 0) { B.lo = hi; B.hi_cur = theta; }
-                __syncthreads();
-                continue;
-            }
-            const bool use_hist = cnt > CAP;
-            float scale = 0.0f;
-            int bstar = kPbBins;
-            if (use_hist) {
-                scale = (float)kPbBins / (mx - mn);
-                if (!(mn < mx) || !(scale < 3.0e38f)) { state = 2; break; }   // > CAP equal (or denormally close) sums
-                for (int b = tid; b < kPbBins; b += NT) B.hist[b] = 0;
-                __syncthreads();
-                for (int i = tid; i < total; i += NT) {
-                    int id; float s;
-                    pb_cand(tab, L.w, i, n1, n2, id, s);
-                    if (s > lo && s <= hi) atomicAdd(&B.hist[(int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1))], 1);
-                }
-                __syncthreads();
-                int dummy;
-                bstar = pb_pick_bins(B, -1, dummy, tid, lane, wave);
-                if (bstar < 0) {   // the first bin alone is too large: zoom into it
-                    if (tid == 0) B.hi_cur = mn + (mx - mn) * (1.0f / (float)kPbBins);
-                    __syncthreads();
-                    continue;
-                }
-            }
-            PB_STAMP(kProfHist);
             if (tid == 0) B.nkeys = 0;
             __syncthreads();
             for (int i = tid; i < total; i += NT) {
                 int id; float s;
                 pb_cand(tab, L.w, i, n1, n2, id, s);
-                bool sel = s > lo && s <= hi;
-                if (sel && use_hist) sel = (int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1)) <= bstar;
-                if (sel) B.keys[atomicAdd(&B.nkeys, 1)] = ((u64)__float_as_uint(s) << 32) | (unsigned)id;
+                if (s <= theta) {
+                    const int slot = atomicAdd(&B.nkeys, 1);
+                    if (slot < CAP) B.gath[slot] = ((u64)__float_as_uint(s) << 32) | (unsigned)id;
+                }
             }
             __syncthreads();
-            PB_STAMP(kProfGather);
+            PB_STAMP(kProfPassA);
             const int n = B.nkeys;
-            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, tid, stop, ntep);
-            if (state) break;
-            if (tid == 0) {
-                if (use_hist) B.lo = __uint_as_float((unsigned)(B.keys[n - 1] >> 32));
-                else { B.lo = hi; B.hi_cur = theta; }
+            if (n <= CAP) {
+                if (n > 0) state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, tid, stop, ntep);
+                if (state == 0 && tid == 0) B.lo = theta;
             }
-            __syncthreads();
         }
         __syncthreads();
+        if constexpr (PROF) {
+            if (tid == 0) {
+                const unsigned long long dt = __builtin_amdgcn_s_memtime() - fstart, dc = B.prof[kProfChunks] - fchunks;
+                B.prof[21] = dt > B.prof[21] ? dt : B.prof[21];
+                B.prof[22] = dc > B.prof[22] ? dc : B.prof[22];
+            }
+        }
         if (state == 2) {   // massive ties: the literal list replay decodes this frame
             if (tid == 0) listB[atomicAdd(&ctl[3], 1)] = (int)f;
             continue;
@@ -751,22 +841,22 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
         if constexpr (PROF) { if (tid == 0) B.prof[kProfFrames] += 1; }
         PB_STAMP(kProfFinish);
     }
-    if constexpr (PROF) { __syncthreads(); if (tid < 16) atomicAdd(&prof_out[tid], B.prof[tid]); }
+    if constexpr (PROF) { __syncthreads(); if (tid < 21) atomicAdd(&prof_out[tid], B.prof[tid]); else if (tid < 24) atomicMax(&prof_out[tid], B.prof[tid]); }
 }
 
 // Stage B of a frame of list C: every TEP with a sum above |y'_0|.  The 43 744 sums are computed once into a
-// per-workgroup global array, histogrammed (1024 bins), and counting-sorted by bin into a second global array;
-// a chunk is then a run of whole bins = a contiguous slice of that array.  A full scan is 3 passes over the
-// TEP table plus ~11 chunks.
+// per-workgroup global array (L2-resident, each thread re-reads what it wrote) and histogrammed (1024 bins); a chunk
+// is then a run of whole bins, gathered by one streaming pass over the cached sums.  A full scan is two passes over
+// the TEP table plus ~11 chunks.
 template <int NT, int CAP, bool PROF>
 __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                       const unsigned char *__restrict__ perm_in,
                                                       const u64 *__restrict__ parity_in, PbParams P,
                                                       const double *__restrict__ cdf_half, const double *__restrict__ coef,
                                                       const uchar4 *__restrict__ tab, float *__restrict__ cache_all,
-                                                      u64 *__restrict__ binned_all, int *__restrict__ ctl,
+                                                      int *__restrict__ ctl,
                                                       const int *__restrict__ listC, int *__restrict__ listB,
-                                                      const PbCarry *__restrict__ carry, PbOut O,
+                                                      const PbCarry *__restrict__ carry, const PbPrep *__restrict__ prep, PbOut O,
                                                       unsigned long long *__restrict__ prof_out)
 {
     constexpr int W = NT / 64;
@@ -775,10 +865,9 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nlist = ctl[5];
     float *cache = cache_all + (size_t)blockIdx.x * kPbTabSize;
-    u64 *binned = binned_all + (size_t)blockIdx.x * kPbTabSize;
     const int nall = P.order == 2 ? kPbTriples0 : kPbTabSize;
     if (tid < 65) B.cdfH[tid] = cdf_half[tid];
-    if constexpr (PROF) { if (tid < 16) B.prof[tid] = 0; if (tid == 0) B.prof_last = __builtin_amdgcn_s_memtime(); }
+    if constexpr (PROF) { if (tid < 24) B.prof[tid] = 0; if (tid == 0) B.prof_last = __builtin_amdgcn_s_memtime(); }
 
     for (;;) {
         __syncthreads();
@@ -788,7 +877,7 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
         if (tk >= nlist) break;
         const long long f = listC[tk];
         const long long src = index ? index[f] : f;
-        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, coef, lane, wave);
+        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, coef, prep, tid);
         if (tid == 0) {
             const PbCarry c = carry[f];
             B.lo = c.lo; B.best = c.best; B.j = c.j; B.nlive = c.nlive; B.cmp = c.cmp; B.suc1 = c.suc1; B.suc2 = c.suc2;
@@ -800,14 +889,25 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
         const u64 d0 = B.d0;
         const float lo = B.lo;    // = |y'_0|
         int stop = 0, ntep = P.nmax, state = 0;
-        // ---- pass 1: all sums once (id == table index when every class is complete)
+        // ---- pass 1: all sums once (id == table index when every class is complete); the table loads of four
+        // TEPs are issued together (the loop is latency-bound: one L2 round trip per trip otherwise)
         int cnt = 0;
         float mn = __builtin_inff(), mx = -1.0f;
-        for (int i = tid; i < nall; i += NT) {
-            int id; float s;
-            pb_cand(tab, L.w, i, 64, kPbTriples0 - kPbPairs0, id, s);
-            cache[i] = s;
-            if (s > lo) { ++cnt; mn = __builtin_fminf(mn, s); mx = __builtin_fmaxf(mx, s); }
+        for (int i = tid; i < nall; i += 4 * NT) {
+            uchar4 t4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t4[u] = tab[i + u * NT < nall ? i + u * NT : 0];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int iu = i + u * NT;
+                if (iu < nall) {
+                    float s = L.w[t4[u].x];
+                    if (t4[u].w > 1) s = s + L.w[t4[u].y];
+                    if (t4[u].w > 2) s = s + L.w[t4[u].z];
+                    cache[iu] = s;
+                    if (s > lo) { ++cnt; mn = __builtin_fminf(mn, s); mx = __builtin_fmaxf(mx, s); }
+                }
+            }
         }
         pb_reduce3(B, cnt, mn, mx, lane, wave);
         PB_STAMP(kProfFill);
@@ -816,7 +916,7 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
             __syncthreads();
             for (int i = tid; i < nall; i += NT) {
                 const float s = cache[i];
-                if (s > lo) B.keys[atomicAdd(&B.nkeys, 1)] = ((u64)__float_as_uint(s) << 32) | (unsigned)i;
+                if (s > lo) B.gath[atomicAdd(&B.nkeys, 1)] = ((u64)__float_as_uint(s) << 32) | (unsigned)i;
             }
             __syncthreads();
             PB_STAMP(kProfGather);
@@ -828,9 +928,13 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
                 // ---- pass 2: histogram; offsets by an exclusive scan over the bins
                 for (int b = tid; b <= kPbBins; b += NT) { if (b < kPbBins) B.hist[b] = 0; B.binoff[b] = 0; }
                 __syncthreads();
-                for (int i = tid; i < nall; i += NT) {
-                    const float s = cache[i];
-                    if (s > lo) atomicAdd(&B.hist[(int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1))], 1);
+                for (int i = tid; i < nall; i += 4 * NT) {
+                    float s4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) s4[u] = i + u * NT < nall ? cache[i + u * NT] : -1.0f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (s4[u] > lo) atomicAdd(&B.hist[(int)__builtin_fminf((s4[u] - mn) * scale, (float)(kPbBins - 1))], 1);
                 }
                 __syncthreads();
                 {
@@ -854,17 +958,9 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
                     __syncthreads();
                 }
                 PB_STAMP(kProfHist);
-                // ---- pass 3: counting sort by bin into the global array
-                for (int i = tid; i < nall; i += NT) {
-                    const float s = cache[i];
-                    if (s > lo) {
-                        const int bin = (int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1));
-                        binned[B.binoff[bin] + atomicAdd(&B.hist[bin], 1)] = ((u64)__float_as_uint(s) << 32) | (unsigned)i;
-                    }
-                }
-                __syncthreads();   // (workgroup-scope release/acquire: the slices below are read by other threads)
-                PB_STAMP(kProfScatter);
-                // ---- chunks: the longest run of whole bins that fits
+                // ---- chunks: the longest run of whole bins that fits, gathered by one streaming pass over the cached sums
+                // (a counting sort of all 43 744 keys into a second global array was measured: its scattered 8-byte stores
+                //  cost as much as eleven such passes, and most frames stop after one or two chunks)
                 int bprev = -1;
                 while (state == 0 && bprev < kPbBins - 1) {
                     const int base = B.binoff[bprev + 1];
@@ -874,6 +970,7 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) { const int t = __shfl_xor(mybest, off, 64); mybest = t > mybest ? t : mybest; }
                     if (lane == 0) B.red_i[1][wave] = mybest;
+                    if (tid == 0) B.nkeys = 0;
                     __syncthreads();
                     int bnext = -1;
 #pragma unroll
@@ -882,7 +979,18 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
                     if (bnext < 0) { state = 2; break; }       // one bin holds more than a chunk: massive ties
                     const int n = B.binoff[bnext + 1] - base;
                     if (n > 0) {
-                        for (int i = tid; i < n; i += NT) B.keys[i] = binned[base + i];
+                        for (int i = tid; i < nall; i += 4 * NT) {
+                            float s4[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) s4[u] = i + u * NT < nall ? cache[i + u * NT] : -1.0f;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (s4[u] > lo) {
+                                    const int bin = (int)__builtin_fminf((s4[u] - mn) * scale, (float)(kPbBins - 1));
+                                    if (bin > bprev && bin <= bnext)
+                                        B.gath[atomicAdd(&B.nkeys, 1)] = ((u64)__float_as_uint(s4[u]) << 32) | (unsigned)(i + u * NT);
+                                }
+                        }
                         __syncthreads();
                         PB_STAMP(kProfGather);
                         state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, tid, stop, ntep);
@@ -901,7 +1009,7 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
         if constexpr (PROF) { if (tid == 0) B.prof[kProfFrames] += 1; }
         PB_STAMP(kProfFinish);
     }
-    if constexpr (PROF) { __syncthreads(); if (tid < 16) atomicAdd(&prof_out[tid], B.prof[tid]); }
+    if constexpr (PROF) { __syncthreads(); if (tid < 21) atomicAdd(&prof_out[tid], B.prof[tid]); else if (tid < 24) atomicMax(&prof_out[tid], B.prof[tid]); }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1116,12 +1224,13 @@ static int stream_ws_pb(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int64_t sp
         (void)hipFree(w.d_pb_list); w.d_pb_list = nullptr; w.pb_cap = 0;
         if (!w.d_pb_ctl && hipMalloc((void **)&w.d_pb_ctl, sizeof(int) * kPbCtlInts) != hipSuccess)
             return fail(LDPC_E_NOMEM, "PB-OSD control words could not be allocated");
-        if (!w.d_pb_cache && (hipMalloc((void **)&w.d_pb_cache, sizeof(float) * (size_t)kPbTabSize * kPbHeavyGrid) != hipSuccess ||
-                              hipMalloc(&w.d_pb_binned, sizeof(u64) * (size_t)kPbTabSize * kPbHeavyGrid) != hipSuccess))
-            return fail(LDPC_E_NOMEM, "PB-OSD sum arrays could not be allocated");
+        if (!w.d_pb_cache && hipMalloc((void **)&w.d_pb_cache, sizeof(float) * (size_t)kPbTabSize * kPbHeavyGrid) != hipSuccess)
+            return fail(LDPC_E_NOMEM, "PB-OSD sum cache could not be allocated");
         (void)hipFree(w.d_pb_carry); w.d_pb_carry = nullptr;
+        (void)hipFree(w.d_pb_prep); w.d_pb_prep = nullptr;
         if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * 3 * (size_t)frames) != hipSuccess ||
-            hipMalloc(&w.d_pb_carry, sizeof(PbCarry) * (size_t)frames) != hipSuccess)
+            hipMalloc(&w.d_pb_carry, sizeof(PbCarry) * (size_t)frames) != hipSuccess ||
+            hipMalloc(&w.d_pb_prep, sizeof(PbPrep) * (size_t)frames) != hipSuccess)
             return fail(LDPC_E_NOMEM, "PB-OSD frame lists for %lld frames could not be allocated", (long long)frames);
         w.pb_cap = frames;
     }
@@ -1155,37 +1264,39 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     const int mode = (p->reserved & 4) ? 2 : ((p->reserved & 2) ? 1 : 0);
     PbOut O{reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep, reinterpret_cast<int *>(p->d_aux)};
     int *listA = w->d_pb_list, *listB = w->d_pb_list + w->pb_cap, *listC = w->d_pb_list + 2 * w->pb_cap;
+    PbPrep *prep_w = reinterpret_cast<PbPrep *>(w->d_pb_prep);
     LDPC_HIP(hipMemsetAsync(w->d_pb_ctl, 0, sizeof(int) * kPbCtlInts, s));
     const int64_t want = (F + 3) / 4;
     const unsigned g1 = (unsigned)(want < 1 ? 1 : (want < 8192 ? want : 8192));
     hipLaunchKernelGGL(pb_singles_kernel, dim3(g1), dim3(256), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
-                       st->d_cdf_half, st->d_coef, w->d_pb_ctl, listA, listB, O);
+                       st->d_cdf_half, st->d_coef, w->d_pb_ctl, listA, listB, prep_w, O);
     const unsigned g2 = (unsigned)(F < 1024 ? F : 1024), g2b = (unsigned)(F < kPbHeavyGrid ? F : kPbHeavyGrid);
     PbCarry *carry = reinterpret_cast<PbCarry *>(w->d_pb_carry);
-    u64 *binned = reinterpret_cast<u64 *>(w->d_pb_binned);
+    const PbPrep *prep = mode == 0 ? prep_w : nullptr;    // (cross-check routes skip the stage that fills it)
     static const bool profile = getenv("LDPC_PB_PROFILE") != nullptr;   // diagnostic build of the two workgroup kernels
     if (!profile) {
         hipLaunchKernelGGL((pb_block_kernel<256, 2048, false>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, O, (unsigned long long *)nullptr);
+                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, (unsigned long long *)nullptr);
         hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, false>), dim3(g2b), dim3(1024), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_cache, binned, w->d_pb_ctl, listC, listB, carry, O,
+                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_cache, w->d_pb_ctl, listC, listB, carry, prep, O,
                            (unsigned long long *)nullptr);
     } else {
         static unsigned long long *d_prof = nullptr;
-        if (!d_prof) LDPC_HIP(hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 32));
-        LDPC_HIP(hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 32, s));
+        if (!d_prof) LDPC_HIP(hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 48));
+        LDPC_HIP(hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 48, s));
         hipLaunchKernelGGL((pb_block_kernel<256, 2048, true>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, O, d_prof);
+                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, d_prof);
         hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, true>), dim3(g2b), dim3(1024), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_cache, binned, w->d_pb_ctl, listC, listB, carry, O, d_prof + 16);
-        unsigned long long h[32];
+                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_cache, w->d_pb_ctl, listC, listB, carry, prep, O, d_prof + 24);
+        unsigned long long h[48];
         LDPC_HIP(hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, s));
         LDPC_HIP(hipStreamSynchronize(s));
-        static const char *names[14] = {"setup", "passA", "hist", "gather", "sort", "tie", "eval1", "eval2", "combine", "fill", "scatter",
-                                        "finish", "FRAMES", "CHUNKS"};
+        static const char *names[24] = {"setup", "passA", "hist", "gather", "sort", "tie", "eval1", "eval2", "combine", "fill", "scatter",
+                                        "finish", "FRAMES", "CHUNKS", "FALLBACKS", "KEYS", "s.minmax", "s.count", "s.scan", "s.scatter",
+                                        "s.fix", "MAXFRAMECYC", "MAXFRAMECHUNKS", "-"};
         for (int k = 0; k < 2; ++k) {
             fprintf(stderr, "[LDPC_PB_PROFILE] %s kernel, cycles of thread 0 summed over workgroups:", k ? "stage-B" : "stage-A");
-            for (int q = 0; q < 14; ++q) fprintf(stderr, " %s=%llu", names[q], h[16 * k + q]);
+            for (int q = 0; q < 23; ++q) fprintf(stderr, " %s=%llu", names[q], h[24 * k + q]);
             fprintf(stderr, "\n");
         }
     }
