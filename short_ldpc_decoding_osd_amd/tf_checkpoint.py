@@ -16,8 +16,10 @@ Format, as published in TensorFlow's sources (tensor_bundle.proto, core/util/ten
   * ``checkpoint`` next to the files is a text proto whose ``model_checkpoint_path`` names the latest prefix.
 
 PARITY UNPINNED: the reference ships no checkpoint and TensorFlow is not installed in the build image, so
-this module is tested only against files written by its own ``write_checkpoint`` (the inverse of the same
-published layout), never against a TensorFlow-written file.  ``weights.load_values_txt`` -- the text mirror
+this module is tested against files written by its own ``write_checkpoint`` and against tables a test builds
+byte by byte the way TensorFlow's table builder lays them out (prefix-compressed keys with restart interval 16,
+several data blocks, two data shards, a compressed block that must be refused) -- never against a
+TensorFlow-written file.  ``weights.load_values_txt`` -- the text mirror
 the training stage writes next to every checkpoint -- is the tested route.
 """
 from __future__ import annotations

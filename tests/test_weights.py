@@ -1,5 +1,7 @@
 """CPU: values.txt weight import.  No trained file ships with the reference, so the
 fixtures are written here in the exact format of ms_decoder_dense.py:338-346."""
+import os
+
 import numpy as np
 import pytest
 
@@ -100,3 +102,104 @@ def test_checkpoint_restores_the_decoder_weight_and_detects_damage(tmp_path):
     other = ck.write_checkpoint(str(tmp_path / "x" / "c-1"), {"unrelated" + ck.VARIABLE_SUFFIX: np.zeros(1, np.float32)})
     with pytest.raises(KeyError):
         ck.load_checkpoint(Model(), other)
+
+
+# ---- reader robustness against what a real TensorFlow writer emits and the module's own writer does not:
+# LevelDB-style tables with prefix-compressed keys (restart interval 16), several data blocks, more than one data
+# shard, and a compressed block (must be refused with a clear message).  The fixtures are built here byte by byte
+# from the published table format (tensorflow/core/lib/io/table_builder.cc, block_builder.cc, format.cc;
+# tensor_bundle.proto) -- still no TensorFlow-written file: parity unpinned.
+def _table(rows, restart_interval=16, block_size=200, tag=0):
+    import struct
+    from short_ldpc_decoding_osd_amd.tfrecord import _varint, masked_crc
+
+    def block(entries):
+        body, restarts, last, n = bytearray(), [], b"", 0
+        for key, value in entries:
+            shared = 0
+            if n % restart_interval == 0:
+                restarts.append(len(body))
+            else:
+                while shared < min(len(key), len(last)) and key[shared] == last[shared]:
+                    shared += 1
+            body += _varint(shared) + _varint(len(key) - shared) + _varint(len(value)) + key[shared:] + value
+            last, n = key, n + 1
+        for r in restarts or [0]:
+            body += struct.pack("<I", r)
+        body += struct.pack("<I", max(len(restarts), 1))
+        tagged = bytes(body) + bytes([tag])
+        return tagged + struct.pack("<I", masked_crc(tagged)), len(body)
+
+    out, index, cur = bytearray(), [], []
+    size = 0
+    for row in rows + [None]:
+        if row is not None:
+            cur.append(row)
+            size += len(row[0]) + len(row[1])
+        if cur and (row is None or size >= block_size):
+            blk, n = block(cur)
+            index.append((cur[-1][0] + b"\x00", _varint(len(out)) + _varint(n)))     # a separator key >= the block's last key
+            out += blk
+            cur, size = [], 0
+    moff = len(out); mb, mn = block([]); out += mb
+    ioff = len(out); ib, isz = block(index); out += ib
+    footer = _varint(moff) + _varint(mn) + _varint(ioff) + _varint(isz)
+    return bytes(out + footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57))
+
+
+def _bundle_rows(tensors, shard_of, nshards):
+    import struct
+    from short_ldpc_decoding_osd_amd import tf_checkpoint as ck
+    from short_ldpc_decoding_osd_amd.tfrecord import _len_field, _varint, masked_crc
+    shards = [bytearray() for _ in range(nshards)]
+    rows = [(b"", _varint((1 << 3) | 0) + _varint(nshards) + _len_field(3, _varint((1 << 3) | 0) + _varint(1)))]
+    for name in sorted(tensors):
+        a = np.asarray(tensors[name])
+        raw, sid = a.tobytes(), shard_of(name)
+        shape = b"".join(_len_field(2, _varint((1 << 3) | 0) + _varint(int(d))) for d in a.shape)
+        entry = (_varint((1 << 3) | 0) + _varint(ck._DTYPE_IDS[np.dtype(a.dtype).str]) + _len_field(2, shape)
+                 + _varint((3 << 3) | 0) + _varint(sid) + _varint((4 << 3) | 0) + _varint(len(shards[sid]))
+                 + _varint((5 << 3) | 0) + _varint(len(raw)) + _varint((6 << 3) | 5) + struct.pack("<I", masked_crc(raw)))
+        rows.append((name.encode(), entry))
+        shards[sid] += raw
+    return rows, shards
+
+
+def test_checkpoint_reader_handles_tensorflow_style_tables(tmp_path):
+    from short_ldpc_decoding_osd_amd import tf_checkpoint as ck
+    rng = np.random.default_rng(1)
+    tensors = {f"myAwesomeModel/layer/w{i:03d}" + ck.VARIABLE_SUFFIX: rng.standard_normal(3 + i % 4).astype(np.float32) for i in range(60)}
+    tensors["myAwesomeModel/layer/shared_check_weight" + ck.VARIABLE_SUFFIX] = np.array([0.25], dtype=np.float32)
+    tensors["save_counter" + ck.VARIABLE_SUFFIX] = np.array(3, dtype=np.int64)
+    rows, shards = _bundle_rows(tensors, lambda name: sum(name.encode()) % 2 if "w0" in name else 0, 2)
+    prefix = str(tmp_path / "ldpc-ckpt-9")
+    open(prefix + ".index", "wb").write(_table(rows))                      # prefix-compressed keys, ~20 data blocks
+    for sid, blob in enumerate(shards):
+        open(f"{prefix}.data-{sid:05d}-of-00002", "wb").write(bytes(blob))
+    header, entries = ck.read_index(prefix + ".index")
+    assert header["num_shards"] == 2 and set(entries) == set(tensors)
+    assert {e["shard_id"] for e in entries.values()} == {0, 1}
+    back = ck.read_checkpoint(prefix)
+    for k, v in tensors.items():
+        assert back[k].dtype == v.dtype and np.array_equal(back[k], v), k
+
+    class Layer:
+        pass
+
+    class Model:
+        layer = Layer()
+
+    assert ck.load_checkpoint(Model(), prefix) == ["shared_check_weight"] and Model.layer.shared_check_weight[0] == np.float32(0.25)
+    # every restart interval gives the same entries
+    for interval in (1, 2, 7, 64):
+        open(prefix + ".index", "wb").write(_table(rows, restart_interval=interval, block_size=1 << 20))     # one big block
+        assert set(ck.read_index(prefix + ".index")[1]) == set(tensors)
+    # a snappy-compressed block (tag 1) is refused, not mis-parsed
+    open(prefix + ".index", "wb").write(_table(rows, tag=1))
+    with pytest.raises(ValueError, match="compressed"):
+        ck.read_index(prefix + ".index")
+    # a missing shard file is a clear error
+    open(prefix + ".index", "wb").write(_table(rows))
+    os.remove(f"{prefix}.data-00001-of-00002")
+    with pytest.raises(FileNotFoundError):
+        ck.read_checkpoint(prefix)
