@@ -125,8 +125,12 @@ int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
         if (p->d_perm && p->d_parity) {   // caller wants the front-end results: two kernels
             if ((rc = ldpc_osd_front(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, nullptr, stream))) return rc;
             if (ev) LDPC_HIP(hipEventRecord(ev[3], s));
-            if ((rc = ldpc_osd_search(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, &p->osd, p->d_cw,
-                                      p->d_metric, p->d_best, p->d_ntep, stream))) return rc;
+            const bool counted = p->d_label_bits && p->d_osd_counts;   // the search kernel counts its own successes where it can
+            if ((rc = osd_search_counted(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, &p->osd, p->d_cw,
+                                         p->d_metric, p->d_best, p->d_ntep, counted ? p->d_label_bits : nullptr,
+                                         counted ? p->d_osd_counts : nullptr, s))) return rc;
+            if (ev) LDPC_HIP(hipEventRecord(ev[4], s));
+            return LDPC_OK;
         } else {                          // ldpc_osd_decode on the context's workspace
             if (ev) LDPC_HIP(hipEventRecord(ev[3], s));
             if ((rc = ldpc_osd_decode(ctx, p->d_llr, p->d_index, p->d_count, p->B, &p->osd, p->d_cw, p->d_metric, p->d_best,

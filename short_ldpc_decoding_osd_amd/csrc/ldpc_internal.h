@@ -78,6 +78,9 @@ int64_t hosd_pattern_teps(int nseg, const int32_t *bounds, const int32_t *patter
 int launch_nms(ldpc_ctx *ctx, const float *d_llr, int64_t B, int T, const float *alpha, float w_in, float w_out,
                float *d_soft, float *d_traj, uint64_t *d_hard, uint8_t *d_fail, int kernel, hipStream_t st);
 int probe_dpp(bool *ror_up, int *wave_rol_dir);
+int osd_search_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                       const uint8_t *d_perm, const uint64_t *d_parity, const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric,
+                       int32_t *d_best, int32_t *d_ntep, const uint64_t *d_label, int64_t *d_counts, hipStream_t s);
 int eval_and_compact(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_label, const uint8_t *d_fail, int64_t B,
                      int64_t *d_counts, int32_t *d_index, int32_t *d_count, hipStream_t st);
 

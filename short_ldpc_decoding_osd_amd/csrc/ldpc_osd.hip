@@ -449,13 +449,17 @@ __global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restric
                                                           const u64 *__restrict__ parity_in, int dir,
                                                           const int *__restrict__ base2,
                                                           u64 *__restrict__ cw_out, float *__restrict__ metric_out,
-                                                          int *__restrict__ best_out, int *__restrict__ ntep_out)
+                                                          int *__restrict__ best_out, int *__restrict__ ntep_out,
+                                                          const u64 *__restrict__ label, u64 *__restrict__ counts)
 {
     __shared__ Search2Lds LL;
     SearchLds &L = LL.s;
     const int lane = threadIdx.x;
     long long nframes = F;
     if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    // the OSD success counters ride along when the caller wants them (ldpc_pipeline_run): {frames, wrong, TEPs};
+    // frames and TEPs are known up front, a wrong codeword costs one fire-and-forget atomic (~6 % of the frames)
+    if (counts && blockIdx.x == 0 && lane == 0) { atomicAdd(&counts[0], (u64)nframes); atomicAdd(&counts[2], (u64)nframes * 2081ull); }
     // software pipeline over the frames of this workgroup: (o, P) two frames ahead, y one frame ahead
     const long long G = gridDim.x;
     long long f0 = blockIdx.x, f1 = f0 + G, f2 = f1 + G;
@@ -471,11 +475,13 @@ __global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restric
         o1b = perm_in[f1 * 128 + lane]; o2b = perm_in[f1 * 128 + 64 + lane]; Pb = parity_in[f1 * 64 + lane];
         srcb = index ? index[f1] : f1;
     }
-    if (f0 < nframes) { y1a = y[srca * 128 + o1a]; y2a = y[srca * 128 + o2a]; }
+    u64 laba = 0;
+    if (f0 < nframes) { y1a = y[srca * 128 + o1a]; y2a = y[srca * 128 + o2a]; if (label && lane < 2) laba = label[srca * 2 + lane]; }
     while (f0 < nframes) {
         // issue the loads of the frames ahead (they are consumed one / two trips later)
         float y1b = 0.0f, y2b = 0.0f;
-        if (f1 < nframes) { y1b = y[srcb * 128 + o1b]; y2b = y[srcb * 128 + o2b]; }
+        u64 labb = 0;
+        if (f1 < nframes) { y1b = y[srcb * 128 + o1b]; y2b = y[srcb * 128 + o2b]; if (label && lane < 2) labb = label[srcb * 2 + lane]; }
         int o1c = 0, o2c = 0;
         u64 Pc = 0;
         long long srcc = 0;
@@ -497,7 +503,16 @@ __global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restric
         wave_fence();
         float best; int bestt; u64 bestD, bestE;
         search2r_device(LL, S, Pa, w1, dir, base2, lane, best, bestt, bestD, bestE);
-        search_finish(L, S, bestE, bestD, f0, lane, cw_out);
+        {   // search_finish, with the codeword words still in hand for the success test (convention_osd.py:65-66)
+            const u64 mrb_bits = S.hm ^ bestE, par_bits = bestD ^ S.hp;
+            if ((mrb_bits >> lane) & 1) atomicOr(&L.cw[S.o1 >> 6], 1ull << (S.o1 & 63));
+            if ((par_bits >> lane) & 1) atomicOr(&L.cw[S.o2 >> 6], 1ull << (S.o2 & 63));
+            wave_fence();
+            const u64 word = lane < 2 ? L.cw[lane] : 0ull;
+            if (lane < 2) cw_out[f0 * 2 + lane] = word;
+            if (counts && __ballot(lane < 2 && word != laba) && lane == 0) atomicAdd(&counts[1], 1ull);
+            wave_fence();
+        }
         if (lane == 0) {
             if (metric_out) metric_out[f0] = best;
             if (best_out) best_out[f0] = bestt;
@@ -505,7 +520,7 @@ __global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restric
         }
         // ---- rotate the pipeline
         f0 = f1; f1 = f2; f2 += G;
-        o1a = o1b; o2a = o2b; Pa = Pb; srca = srcb; y1a = y1b; y2a = y2b;
+        o1a = o1b; o2a = o2b; Pa = Pb; srca = srcb; y1a = y1b; y2a = y2b; laba = labb;
         o1b = o1c; o2b = o2c; Pb = Pc; srcb = srcc;
     }
 }
@@ -822,10 +837,14 @@ static int check_params(ldpc_ctx *ctx, const ldpc_osd_params *p, const char *who
 }
 
 // launches the search kernel selected by p->algo on front-end results (d_perm, d_parity)
+// label / counts / fused: the success counters of ldpc_osd_counts accumulated by the search kernel itself where it can
+// (*fused is set then, and the caller skips the separate counting launch)
 static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
                          const unsigned char *d_perm, const u64 *d_parity, const ldpc_osd_params *p, uint64_t *d_cw,
-                         float *d_metric, int32_t *d_best, int32_t *d_ntep, hipStream_t s)
+                         float *d_metric, int32_t *d_best, int32_t *d_ntep, hipStream_t s, const uint64_t *d_label = nullptr,
+                         int64_t *d_counts = nullptr, bool *fused = nullptr)
 {
+    if (fused) *fused = false;
     OsdState *st = state(ctx);
     if (p->algo == LDPC_OSD_PB) {
         return launch_pb(ctx, d_y, d_index, d_count, F, d_perm, d_parity, p, d_cw, d_metric, d_best, d_ntep, s);
@@ -844,7 +863,9 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
         // frame (measured, 33 487 frames: 1x 119 us, 2x 117, 3x 108, 4x 107, 6x 100, 9x 102 per call incl. events)
         const long long grid = (long long)ctx->cu_count * 14 * 6;
         hipLaunchKernelGGL(osd_search2r_kernel, dim3((unsigned)(F < grid ? F : grid)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
-                           d_perm, d_parity, ctx->dpp_wave_rol_dir, st->d_base2, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
+                           d_perm, d_parity, ctx->dpp_wave_rol_dir, st->d_base2, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep,
+                           reinterpret_cast<const u64 *>(d_label), d_label ? reinterpret_cast<u64 *>(d_counts) : nullptr);
+        if (fused && d_label && d_counts) *fused = true;
     } else if (p->order == 2 && !(p->reserved & 1)) {
         hipLaunchKernelGGL(osd_search2_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
                            d_perm, d_parity, st->d_base2, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep);
@@ -861,6 +882,29 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;
 }
+
+}  // extern "C"
+
+namespace ldpc {
+// ldpc_osd_search + ldpc_osd_counts for ldpc_pipeline_run: one launch where the search kernel can count itself
+int osd_search_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                       const uint8_t *d_perm, const uint64_t *d_parity, const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric,
+                       int32_t *d_best, int32_t *d_ntep, const uint64_t *d_label, int64_t *d_counts, hipStream_t s)
+{
+    if (!ctx || !p || F < 0 || (F > 0 && (!d_y || !d_cw || !d_perm || !d_parity)))
+        return fail(LDPC_E_ARG, "ldpc_osd_search: bad arguments");
+    int rc = check_params(ctx, p, "ldpc_osd_search");
+    if (rc) return rc;
+    if (F == 0) return LDPC_OK;
+    bool fused = false;
+    rc = launch_search(ctx, d_y, d_index, d_count, F, d_perm, reinterpret_cast<const u64 *>(d_parity), p, d_cw, d_metric, d_best, d_ntep,
+                       s, d_label, d_counts, &fused);
+    if (rc || fused || !d_label || !d_counts) return rc;
+    return ldpc_osd_counts(ctx, d_cw, d_label, d_index, d_count, d_ntep, F, d_counts, s);
+}
+}  // namespace ldpc
+
+extern "C" {
 
 int ldpc_osd_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
                     const uint8_t *d_perm, const uint64_t *d_parity, const ldpc_osd_params *p, uint64_t *d_cw,

@@ -138,14 +138,33 @@ __global__ __launch_bounds__(kCompactThreads) void compact_kernel(const unsigned
         const long long fb = c0 + threadIdx.x * FPT;
         const unsigned bits = fb < hi ? flags_of<FPT>(flag, fb, hi, al16) : 0;
         const int mine = __popc(bits);
-        if constexpr (EVAL) {   // frame c0 + q NT + thread: coalesced 16-byte loads of the hard words and labels
+        if constexpr (EVAL) {   // frame c0 + q NT + thread: coalesced loads of the hard words and labels
+            if (words == 2) {   // n = 128: every load of the step is issued before the first is used (one memory latency)
+                ulonglong2 hv[FPT], lv[FPT];
+                unsigned char fv[FPT];
 #pragma unroll
-            for (int q = 0; q < FPT; ++q) {
-                const long long f = c0 + q * NT + threadIdx.x;
-                if (f < hi) {
-                    int e = 0;
-                    for (int w = 0; w < words; ++w) e += __popcll(hard[f * words + w] ^ label[f * words + w]);
-                    cnt += 1; berr += e; ferr += e != 0; und += (flag[f] == 0 && e != 0);
+                for (int q = 0; q < FPT; ++q) {
+                    const long long f = c0 + q * NT + threadIdx.x, fc = f < hi ? f : lo;
+                    hv[q] = *reinterpret_cast<const ulonglong2 *>(hard + fc * 2);
+                    lv[q] = *reinterpret_cast<const ulonglong2 *>(label + fc * 2);
+                    fv[q] = flag[fc];
+                }
+#pragma unroll
+                for (int q = 0; q < FPT; ++q) {
+                    if (c0 + q * NT + threadIdx.x < hi) {
+                        const int e = __popcll(hv[q].x ^ lv[q].x) + __popcll(hv[q].y ^ lv[q].y);
+                        cnt += 1; berr += e; ferr += e != 0; und += (fv[q] == 0 && e != 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < FPT; ++q) {
+                    const long long f = c0 + q * NT + threadIdx.x;
+                    if (f < hi) {
+                        int e = 0;
+                        for (int w = 0; w < words; ++w) e += __popcll(hard[f * words + w] ^ label[f * words + w]);
+                        cnt += 1; berr += e; ferr += e != 0; und += (flag[f] == 0 && e != 0);
+                    }
                 }
             }
         }
