@@ -16,16 +16,18 @@
 //                       ~12 VALU ops, row exchanges only touch a lane-resident row map and column
 //                       exchanges move two lanes.  Output: perm (original bit at each primed
 //                       position) and the rows of P' (G' = [I | P']) after a 64x64 bit transpose.
-//   osd_search2_kernel  conventional order 2, register-resident, two-stage scan with an exact
-//                       prefix early exit and survivor compaction (the headline configuration).
+//   osd_search2r_kernel conventional order 2 (the headline configuration): register-resident, rotation pairing by
+//                       wave_rol DPP, two-stage scan with an exact prefix early exit and survivor compaction,
+//                       software-pipelined LUT reads, prefetched inputs, success counters on request.
+//   osd_search2_kernel  the round-1 form of the same scan (v_readlane pairing): fallback and cross-check route.
 //   osd_search_kernel   conventional order-p search over the reference's TEP table: per frame a
 //                       byte-indexed LUT of partial |y'| sums in LDS (8 x 256 floats), each lane
 //                       evaluates one TEP per round: parity word = d0 ^ P'[i] ^ P'[j] ..., metric
 //                       = flipped-MRB weights + 8 LUT terms in a FIXED order (the canonical order
 //                       the oracle uses, see oracle/np_oracle.py weighted_distance), first minimum.
 //   osd_fs_kernel       FS-OSD (FS_OSD/fs_testing.py:22-64,129-161), 64 TEPs per round.
-//   osd_pb_kernel       PB-OSD (PB_OSD/pb_testing.py:35-41,100-149,366-500), best-first frontier.
 //   osd_ge_kernel       full_gf2elim on caller-supplied matrices; osd_counts_kernel: success counters.
+//   (PB-OSD: ldpc_osd_pb.hip; shared per-frame set-up: ldpc_search.h; host state: ldpc_osd_state.h)
 #include <math.h>
 #include <stdlib.h>
 
