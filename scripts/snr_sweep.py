@@ -66,6 +66,13 @@ def main():
     lo, hi = shard_range(args.frames, rank, world)
     mine = hi - lo
     gen = torch.Generator(device=dec.device).manual_seed(rank_seed(20241020, rank))
+    # warm-up: workspaces of the stream (OSD front-end results, PB-OSD lists / caches) are allocated on the first call
+    yw, lw = frames_on_device(dec, min(args.batch, mine, 8192) or 1, float(args.snr[0]), torch.Generator(device=dec.device).manual_seed(1))
+    BatchPipeline(dec, yw.shape[0], args.iters, alpha, osd_order=args.order, osd_algo=ALGOS[args.osd], snr_db=float(args.snr[0]),
+                  want_soft=False, keep_front=False).bind(yw, lw).run()
+    if mine >= args.batch:
+        dec.osd_reserve(args.batch)
+    torch.cuda.synchronize()
     for snr in np.linspace(float(args.snr[0]), float(args.snr[1]), int(args.snr[2])):
         snr = round(float(snr), 2)
         total = torch.zeros(8, dtype=torch.int64, device=dec.device)

@@ -710,8 +710,6 @@ int osd_ctx_init(ldpc_ctx *ctx)
         for (int i = 0; i < 64; ++i) { t = t * coef[i] * (0.5 / 0.5); acc = acc + t; cdf[i + 1] = acc; }
         LDPC_HIP(hipMalloc((void **)&st->d_cdf_half, sizeof(cdf)));
         LDPC_HIP(hipMemcpy(st->d_cdf_half, cdf, sizeof(cdf), hipMemcpyHostToDevice));
-        LDPC_HIP(hipMalloc((void **)&st->d_coef, sizeof(coef)));
-        LDPC_HIP(hipMemcpy(st->d_coef, coef, sizeof(coef), hipMemcpyHostToDevice));
     }
     if (int rc = pb_ctx_init(ctx)) return rc;
     ctx->osd_ok = true;
@@ -731,7 +729,6 @@ void osd_ctx_release(ldpc_ctx *ctx)
         (void)hipFree(st->d_tep_fs);
         (void)hipFree(st->d_base2);
         (void)hipFree(st->d_cdf_half);
-        (void)hipFree(st->d_coef);
         (void)hipFree(st->d_pb_tab);
         delete st;
     }

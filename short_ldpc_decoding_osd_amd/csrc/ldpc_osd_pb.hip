@@ -118,8 +118,7 @@ struct PbFrame {
 
 // One wavefront: q[p] = sigmoid(c4 |y'_p|), the binomial CDF table of the mean LRB error probability and
 // the two thresholds.  L.w must be in place; q / cdfA are per-frame LDS arrays.
-__device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, double *cdfA, const double *__restrict__ coef,
-                                                  float c4, int order, int nmax, int lane)
+__device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, double *cdfA, float c4, int order, int nmax, int lane)
 {
     q[lane] = 1.0f / (1.0f + det_expf(-(c4 * L.w[lane])));
     q[lane + 64] = 1.0f / (1.0f + det_expf(-(c4 * L.w[lane + 64])));
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(256) void pb_singles_kernel(const float *__restrict
                                                          const int *__restrict__ count, long long F,
                                                          const unsigned char *__restrict__ perm_in,
                                                          const u64 *__restrict__ parity_in, PbParams P, int mode,
-                                                         const double *__restrict__ cdf_half, const double *__restrict__ coef,
+                                                         const double *__restrict__ cdf_half,
                                                          int *__restrict__ ctl, int *__restrict__ listA, int *__restrict__ listB,
                                                          PbPrep *__restrict__ prep, PbOut O)
 {
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(256) void pb_singles_kernel(const float *__restrict
     for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
         const long long src = index ? index[f] : f;
         const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
-        const PbFrame Fr = pb_frame_setup(L, W.q, W.cdfA, coef, P.c4, P.order, P.nmax, lane);
+        const PbFrame Fr = pb_frame_setup(L, W.q, W.cdfA, P.c4, P.order, P.nmax, lane);
         pb_success_terms(W.q, W.tq, lane);
         wave_fence();
         const float best0 = tep_cost(L, 0.0f, S.d0);
@@ -717,7 +716,7 @@ struct PbCarry {
 template <int NT, int CAP>
 __device__ __forceinline__ SearchFrame pb_block_setup(PbBlockLds<NT, CAP> &B, const float *__restrict__ y, long long src, long long f,
                                                       const unsigned char *__restrict__ perm_in, const u64 *__restrict__ parity_in,
-                                                      const PbParams &P, const double *__restrict__ coef, const PbPrep *__restrict__ prep,
+                                                      const PbParams &P, const PbPrep *__restrict__ prep,
                                                       int tid)
 {
     SearchLds &L = B.s;
@@ -736,7 +735,7 @@ __device__ __forceinline__ SearchFrame pb_block_setup(PbBlockLds<NT, CAP> &B, co
     for (int b = wave; b < 8; b += NT / 64) build_byte_luts<1>(L.lut + b, &L.w[64 + 8 * b], lane);
     if (wave == 0) {
         if (!prep) {
-            const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, coef, P.c4, P.order, P.nmax, lane);
+            const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, P.c4, P.order, P.nmax, lane);
             if (lane == 0) B.fr = Fr;
         }
         pb_success_terms(B.q, B.tq, lane);
@@ -752,7 +751,7 @@ template <int NT, int CAP, bool PROF>
 __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                       const unsigned char *__restrict__ perm_in,
                                                       const u64 *__restrict__ parity_in, PbParams P,
-                                                      const double *__restrict__ cdf_half, const double *__restrict__ coef,
+                                                      const double *__restrict__ cdf_half,
                                                       const uchar4 *__restrict__ tab, int *__restrict__ ctl,
                                                       const int *__restrict__ listA, int *__restrict__ listB,
                                                       int *__restrict__ listC, PbCarry *__restrict__ carry,
@@ -774,7 +773,7 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
         if (tk >= nlist) break;
         const long long f = listA[tk];
         const long long src = index ? index[f] : f;
-        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, coef, prep, tid);
+        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, prep, tid);
         if (tid == 0) {
             B.lo = -1.0f; B.hi_cur = L.w[0];
             B.j = 0; B.nlive = 1; B.cmp = 0; B.suc1 = 0; B.suc2 = 0; B.bestidx = 0;
@@ -852,7 +851,7 @@ template <int NT, int CAP, bool PROF>
 __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                       const unsigned char *__restrict__ perm_in,
                                                       const u64 *__restrict__ parity_in, PbParams P,
-                                                      const double *__restrict__ cdf_half, const double *__restrict__ coef,
+                                                      const double *__restrict__ cdf_half,
                                                       const uchar4 *__restrict__ tab, float *__restrict__ cache_all,
                                                       int *__restrict__ ctl,
                                                       const int *__restrict__ listC, int *__restrict__ listB,
@@ -877,7 +876,7 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
         if (tk >= nlist) break;
         const long long f = listC[tk];
         const long long src = index ? index[f] : f;
-        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, coef, prep, tid);
+        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, prep, tid);
         if (tid == 0) {
             const PbCarry c = carry[f];
             B.lo = c.lo; B.best = c.best; B.j = c.j; B.nlive = c.nlive; B.cmp = c.cmp; B.suc1 = c.suc1; B.suc2 = c.suc2;
@@ -1019,7 +1018,7 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
 __global__ __launch_bounds__(256) void pb_seq_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                      const unsigned char *__restrict__ perm_in,
                                                      const u64 *__restrict__ parity_in, PbParams P,
-                                                     const double *__restrict__ cdf_half, const double *__restrict__ coef,
+                                                     const double *__restrict__ cdf_half,
                                                      PbEntry *__restrict__ spill_all, long long spill_stride,
                                                      int *__restrict__ ctl, const int *__restrict__ listB, PbOut O)
 {
@@ -1044,7 +1043,7 @@ __global__ __launch_bounds__(256) void pb_seq_kernel(const float *__restrict__ y
         const long long f = listB[tk];
         const long long src = index ? index[f] : f;
         const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
-        const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, coef, P.c4, P.order, P.nmax, lane);
+        const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, P.c4, P.order, P.nmax, lane);
         const float spl = Fr.spl, lrb_mean = Fr.lrb_mean;
         const double p_t_suc = Fr.p_t_suc, p_t_pro = Fr.p_t_pro;
         if (lane == 0) {   // starting point: the single TEP {k-1} (pb_testing.py:109-110)
@@ -1269,25 +1268,25 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     const int64_t want = (F + 3) / 4;
     const unsigned g1 = (unsigned)(want < 1 ? 1 : (want < 8192 ? want : 8192));
     hipLaunchKernelGGL(pb_singles_kernel, dim3(g1), dim3(256), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
-                       st->d_cdf_half, st->d_coef, w->d_pb_ctl, listA, listB, prep_w, O);
+                       st->d_cdf_half, w->d_pb_ctl, listA, listB, prep_w, O);
     const unsigned g2 = (unsigned)(F < 1024 ? F : 1024), g2b = (unsigned)(F < kPbHeavyGrid ? F : kPbHeavyGrid);
     PbCarry *carry = reinterpret_cast<PbCarry *>(w->d_pb_carry);
     const PbPrep *prep = mode == 0 ? prep_w : nullptr;    // (cross-check routes skip the stage that fills it)
     static const bool profile = getenv("LDPC_PB_PROFILE") != nullptr;   // diagnostic build of the two workgroup kernels
     if (!profile) {
         hipLaunchKernelGGL((pb_block_kernel<256, 2048, false>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, (unsigned long long *)nullptr);
+                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, (unsigned long long *)nullptr);
         hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, false>), dim3(g2b), dim3(1024), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_cache, w->d_pb_ctl, listC, listB, carry, prep, O,
+                           st->d_cdf_half, st->d_pb_tab, w->d_pb_cache, w->d_pb_ctl, listC, listB, carry, prep, O,
                            (unsigned long long *)nullptr);
     } else {
         static unsigned long long *d_prof = nullptr;
         if (!d_prof) LDPC_HIP(hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 48));
         LDPC_HIP(hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 48, s));
         hipLaunchKernelGGL((pb_block_kernel<256, 2048, true>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, d_prof);
+                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, d_prof);
         hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, true>), dim3(g2b), dim3(1024), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_coef, st->d_pb_tab, w->d_pb_cache, w->d_pb_ctl, listC, listB, carry, prep, O, d_prof + 24);
+                           st->d_cdf_half, st->d_pb_tab, w->d_pb_cache, w->d_pb_ctl, listC, listB, carry, prep, O, d_prof + 24);
         unsigned long long h[48];
         LDPC_HIP(hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, s));
         LDPC_HIP(hipStreamSynchronize(s));
@@ -1301,7 +1300,7 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
         }
     }
     const unsigned g3 = (unsigned)(want < kPbSeqBlocks ? (want < 1 ? 1 : want) : kPbSeqBlocks);
-    hipLaunchKernelGGL(pb_seq_kernel, dim3(g3), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half, st->d_coef,
+    hipLaunchKernelGGL(pb_seq_kernel, dim3(g3), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half,
                        reinterpret_cast<PbEntry *>(w->d_pb_spill), (long long)w->pb_spill_stride, w->d_pb_ctl, listB, O);
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;

@@ -30,7 +30,6 @@ struct OsdState {
     uchar4 *d_tep_fs = nullptr;       // FS visit order, weight classes 1..3 back to back
     int *d_base2 = nullptr;           // order-2 ranks: number of index pairs with a larger sum
     double *d_cdf_half = nullptr;     // PB-OSD: P[Bin(64, 1/2) <= b], b = 0..64
-    double *d_coef = nullptr;         // PB-OSD: (64-i)/(i+1)
     uchar4 *d_pb_tab = nullptr;       // PB-OSD: TEPs by weight class, each class by descending smallest position (pb_tables)
     int fs_off[4] = {0, 0, 0, 0}, fs_cnt[4] = {0, 0, 0, 0};
     std::mutex mu;                    // guards `ws` and `reserve_frames`
