@@ -217,6 +217,15 @@ int ldpc_osd_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
                     const ldpc_osd_params *params, uint64_t *d_cw, float *d_metric, int32_t *d_best, int32_t *d_ntep,
                     void *stream);
 
+/* One GIVEN test error pattern per frame on front-end results: one_tep_compare, FS_OSD/fs_testing.py:51-64
+ * (re-encode the MRB hard decisions with the positions of d_mask[f] flipped; its (:58-62) Hamming and weighted
+ * distances to the hard decisions of y').  Any weight.  Same LUT evaluation and float order as the searches.
+ *   d_mask   [F] u64   bit p = flip MRB position p (primed order)
+ *   d_cw     [F][2] u64 candidate codeword, ORIGINAL bit order;  d_metric [F] f32 (nullable);  d_hd [F] i32 (nullable) */
+int ldpc_osd_tep_eval(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                      const uint8_t *d_perm, const uint64_t *d_parity, const uint64_t *d_mask, uint64_t *d_cw,
+                      float *d_metric, int32_t *d_hd, void *stream);
+
 /* OSD statistics against labels: d_counts[3] += {frames, frames_wrong, teps_total}.
  * (the success test of convention_osd.py:65-66 / pb_testing.py:158 / fs_testing.py:162)   */
 int ldpc_osd_counts(ldpc_ctx *ctx, const uint64_t *d_cw, const uint64_t *d_label_bits, const int32_t *d_index,

@@ -18,7 +18,7 @@ SYMBOLS = (
     "ldpc_code_get_H", "ldpc_code_get_G", "ldpc_gf2elim_host", "ldpc_tep_table", "ldpc_tep_table_fs", "ldpc_crc32c",
     "ldpc_ctx_create", "ldpc_ctx_destroy", "ldpc_ctx_nms_kernel",
     "ldpc_nms_decode", "ldpc_eval_counts", "ldpc_compact", "ldpc_pack_bits", "ldpc_unpack_bits",
-    "ldpc_osd_reserve", "ldpc_osd_reserve_stream", "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_search", "ldpc_osd_decode", "ldpc_osd_counts",
+    "ldpc_osd_reserve", "ldpc_osd_reserve_stream", "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_search", "ldpc_osd_decode", "ldpc_osd_tep_eval", "ldpc_osd_counts",
     "ldpc_hosd_pattern_teps", "ldpc_hosd_front", "ldpc_hosd_search",
     "ldpc_pipeline_run", "ldpc_pipeline_timing",
 )
@@ -95,6 +95,7 @@ def load():
         "ldpc_osd_front": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp]),
         "ldpc_osd_search": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, C.POINTER(OsdParams), vp, vp, vp, vp, vp]),
         "ldpc_osd_decode": (C.c_int, [vp, vp, vp, vp, i64, C.POINTER(OsdParams), vp, vp, vp, vp, vp]),
+        "ldpc_osd_tep_eval": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]),
         "ldpc_osd_counts": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, vp]),
         "ldpc_hosd_pattern_teps": (i64, [i32, pi32, pi32, C.POINTER(C.c_uint8)]),
         "ldpc_hosd_front": (C.c_int, [vp, vp, i64, vp, vp, vp, vp, vp]),

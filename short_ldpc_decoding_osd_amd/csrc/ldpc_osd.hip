@@ -618,6 +618,39 @@ __global__ __launch_bounds__(64) void osd_fs_kernel(const float *__restrict__ y,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// One given TEP per frame (one_tep_compare, FS_OSD/fs_testing.py:51-64): re-encode the MRB hard decisions with the
+// positions of `mask` flipped, Hamming distance and weighted distance of the candidate -- the SAME LUT evaluation and
+// float order as the searches (the Python helper of that name used to restate the order in NumPy).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void osd_tep_eval_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                           const int *__restrict__ count, long long F,
+                                                           const unsigned char *__restrict__ perm_in,
+                                                           const u64 *__restrict__ parity_in, const u64 *__restrict__ mask,
+                                                           u64 *__restrict__ cw_out, float *__restrict__ metric_out,
+                                                           int *__restrict__ hd_out)
+{
+    __shared__ SearchLds lds[4];
+    const int lane = threadIdx.x & 63;
+    SearchLds &L = lds[threadIdx.x >> 6];
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    for (long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); f < nframes; f += (long long)gridDim.x * 4) {
+        const long long src = index ? index[f] : f;
+        const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+        const u64 E = mask[f];
+        const u64 D = S.d0 ^ wave_xor64(((E >> lane) & 1) ? L.P[lane] : 0ull);
+        float mrb = 0.0f;                                  // flipped MRB weights, ascending position, sequential
+        for (u64 m = E; m; m &= m - 1) mrb = mrb + L.w[__builtin_ctzll(m)];
+        const float cost = tep_cost(L, mrb, D);
+        search_finish(L, S, E, D, f, lane, cw_out);
+        if (lane == 0) {
+            if (metric_out) metric_out[f] = cost;
+            if (hd_out) hd_out[f] = __popcll(E) + __popcll(D);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void osd_counts_kernel(const u64 *__restrict__ cw, const u64 *__restrict__ label,
                                                          const int *__restrict__ index, const int *__restrict__ count,
                                                          const int *__restrict__ ntep, long long F,
@@ -932,6 +965,21 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
     hipLaunchKernelGGL(osd_front_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
                        reinterpret_cast<const u64 *>(ctx->d_Gcols), w->d_perm, w->d_parity, (int *)nullptr);
     return launch_search(ctx, d_y, d_index, d_count, F, w->d_perm, w->d_parity, p, d_cw, d_metric, d_best, d_ntep, s);
+}
+
+int ldpc_osd_tep_eval(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                      const uint8_t *d_perm, const uint64_t *d_parity, const uint64_t *d_mask, uint64_t *d_cw, float *d_metric,
+                      int32_t *d_hd, void *stream)
+{
+    if (!ctx || F < 0 || (F > 0 && (!d_y || !d_perm || !d_parity || !d_mask || !d_cw)))
+        return fail(LDPC_E_ARG, "ldpc_osd_tep_eval: bad arguments");
+    if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
+    if (F == 0) return LDPC_OK;
+    hipLaunchKernelGGL(osd_tep_eval_kernel, dim3(osd_grid(F)), dim3(256), 0, (hipStream_t)stream, d_y, d_index, d_count, (long long)F,
+                       d_perm, reinterpret_cast<const u64 *>(d_parity), reinterpret_cast<const u64 *>(d_mask),
+                       reinterpret_cast<u64 *>(d_cw), d_metric, d_hd);
+    LDPC_HIP(hipGetLastError());
+    return LDPC_OK;
 }
 
 int ldpc_osd_counts(ldpc_ctx *ctx, const uint64_t *d_cw, const uint64_t *d_label_bits, const int32_t *d_index,

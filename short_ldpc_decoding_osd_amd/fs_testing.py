@@ -55,26 +55,26 @@ def generate_sequential_teps(max_value, max_loops):
 
 
 def one_tep_compare(updated_inputs, nth_tep, reduced_G, threshold):
-    """(early_stopping, codeword [1,128], weighted distance) of one TEP (:51-64): evaluated on the
-    device as an order-|tep| FS scan restricted to... nothing smaller than a full search kernel
-    exists per TEP, so this helper re-encodes on the host from ``reduced_G`` (it is not on the
-    batched path, which lives in ``fs_osd``)."""
-    y = np.asarray(updated_inputs, dtype=np.float32)
+    """(early_stopping, codeword [1,128], weighted distance) of one TEP (:51-64), evaluated on the device by
+    ``ldpc_osd_tep_eval`` -- the searches' own LUT evaluation and float order -- on the primed-order inputs
+    (identity permutation) and the parity part of ``reduced_G``.  (Not on the batched path, which lives in ``fs_osd``.)"""
+    import torch
+    from .runtime import default_decoder
+    dec = default_decoder(GL.get_map('code_parameters'))
+    y = torch.from_numpy(np.ascontiguousarray(np.asarray(updated_inputs, dtype=np.float32).reshape(1, -1))).to(dec.device)
     G = np.asarray(reduced_G, dtype=np.int64)
-    hard = np.where(y > 0, 0, 1).astype(np.int64)
-    mrb = (hard[:G.shape[0]] + np.asarray(nth_tep, dtype=np.int64)) % 2
-    cw = mrb.dot(G) % 2
-    disc = (cw + hard) % 2
-    acc = np.float32(0)                       # canonical order: MRB part, then parity bytes
-    for p in np.flatnonzero(disc[:64]):
-        acc = np.float32(acc + abs(y[p]))
-    for b in range(8):
-        part = np.float32(0)
-        for p in range(64 + 8 * b, 72 + 8 * b):
-            if disc[p]:
-                part = np.float32(part + abs(y[p]))
-        acc = np.float32(acc + part)
-    return bool(float(disc.sum()) < threshold), cw.reshape(1, -1).astype(np.int32), acc
+    k = G.shape[0]
+    rows = np.packbits(G[:, k:].astype(np.uint8), axis=1, bitorder="little").view(np.uint64).reshape(1, k)
+    perm = torch.arange(128, dtype=torch.uint8, device=dec.device).reshape(1, 128)
+    parity = torch.from_numpy(rows.view(np.int64)).to(dec.device)
+    mask = np.uint64(0)
+    for p in np.flatnonzero(np.asarray(nth_tep)):
+        mask |= np.uint64(1) << np.uint64(p)
+    out = dec.osd_tep_eval(y, perm, parity, torch.from_numpy(np.array([mask]).view(np.int64)).to(dec.device))
+    torch.cuda.synchronize()
+    words = out["cw"].cpu().numpy().view(np.uint64)[0]
+    cw = np.unpackbits(words.view(np.uint8), bitorder="little").astype(np.int32).reshape(1, -1)
+    return bool(float(out["hd"].cpu()[0]) < threshold), cw, np.float32(out["metric"].cpu()[0])
 
 
 def fs_osd(snr, beta, selected_ds, intended=False):

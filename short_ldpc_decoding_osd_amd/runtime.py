@@ -209,6 +209,19 @@ class Decoder:
                                           _ptr(out["ntep"]), self._stream()), "ldpc_osd_search")
         return out
 
+    def osd_tep_eval(self, y, perm, parity, mask, index=None, count=None):
+        """One given TEP per frame (mask [F] int64: bit p flips primed MRB position p) on front-end results.
+        Returns dict(cw[F,2] int64 original bit order, metric[F] f32, hd[F] i32)."""
+        self._chk(y, torch.float32, (self.n,), "y")
+        self._chk(perm, torch.uint8, (128,), "perm")
+        self._chk(parity, torch.int64, (64,), "parity")
+        self._chk(mask, torch.int64, (), "mask")
+        F = perm.shape[0]
+        out = dict(cw=self.empty((F, 2), torch.int64), metric=self.empty((F,), torch.float32), hd=self.empty((F,), torch.int32))
+        _lib.check(self.L.ldpc_osd_tep_eval(self._ctx, _ptr(y), _ptr(index), _ptr(count), F, _ptr(perm), _ptr(parity), _ptr(mask),
+                                            _ptr(out["cw"]), _ptr(out["metric"]), _ptr(out["hd"]), self._stream()), "ldpc_osd_tep_eval")
+        return out
+
     # ------------------------------------------------------------------ H-form OSD (DL-OSD stage)
     def hosd_front(self, order_llr):
         """check_matrix_reorder + identify_mrb on [F,128] ordering values.  Returns (lri[F,128] u8,

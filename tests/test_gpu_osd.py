@@ -243,3 +243,32 @@ def test_single_call_pipeline_equals_the_separate_calls(dec):
     refpb = c_oracle.pb_osd(dec.code.G, y[index[:nf].cpu().numpy()], cw[index[:nf].cpu().numpy()], 2, 2.5)
     assert np.array_equal(p3.ntep[:nf].cpu().numpy(), refpb["num_teps"])
     assert p3.counters().cpu().numpy()[6] == int((~refpb["correct"]).sum())
+
+
+def test_tep_eval_matches_oracle(dec):
+    """ldpc_osd_tep_eval (one_tep_compare, fs_testing.py:51-64): a GIVEN error pattern of any weight per frame, on the
+    device front end's results, against the NumPy restatement (re-encode, Hamming and canonical weighted distance)."""
+    rng = np.random.default_rng(77)
+    y, cw = np_oracle.make_frames(dec.code.G, 2.0, 300, rng)
+    yd = to_dev(y, dec)
+    perm, parity, _ = dec.osd_front(yd)
+    weights = rng.integers(0, 7, size=300)
+    masks = np.zeros(300, dtype=np.uint64)
+    for f in range(300):
+        for p in rng.choice(64, size=weights[f], replace=False):
+            masks[f] |= np.uint64(1) << np.uint64(p)
+    out = dec.osd_tep_eval(yd, perm, parity, to_dev(masks.view(np.int64), dec))
+    torch.cuda.synchronize()
+    got_cw, got_m, got_hd = words_np(out["cw"]), out["metric"].cpu().numpy(), out["hd"].cpu().numpy()
+    for f in range(0, 300, 3):
+        yp, lp, Gp, pm, _ = np_oracle.swapped_info(y[f], cw[f], dec.code.G)
+        assert np.array_equal(perm[f].cpu().numpy(), pm)
+        hard = np.where(yp > 0, 0, 1).astype(np.int64)
+        e = np.array([(int(masks[f]) >> p) & 1 for p in range(64)], dtype=np.int64)
+        cand = ((hard[:64] + e) % 2).dot(Gp) % 2
+        disc = (cand + hard) % 2
+        assert got_hd[f] == disc.sum()
+        assert got_m[f] == np_oracle.weighted_distance(disc, np.abs(yp))
+        orig = np.empty(128, dtype=np.int64)
+        orig[pm] = cand
+        assert np.array_equal(got_cw[f], pack_np(orig[None])[0])
