@@ -844,9 +844,9 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
 }
 
 // Stage B of a frame of list C: every TEP with a sum above |y'_0|.  The 43 744 sums are computed once into a
-// per-workgroup global array (L2-resident, each thread re-reads what it wrote) and histogrammed (1024 bins); a chunk
-// is then a run of whole bins, gathered by one streaming pass over the cached sums.  A full scan is two passes over
-// the TEP table plus ~11 chunks.
+// per-workgroup global array (L2-resident, each thread re-reads what it wrote) and histogrammed (1024 bins over an
+// a-priori range) in the same pass; a chunk is then a run of whole bins, gathered by one streaming pass over the
+// cached sums.  A full scan is one pass over the TEP table plus ~11 chunks.
 template <int NT, int CAP, bool PROF>
 __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                       const unsigned char *__restrict__ perm_in,
@@ -888,10 +888,15 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
         const u64 d0 = B.d0;
         const float lo = B.lo;    // = |y'_0|
         int stop = 0, ntep = P.nmax, state = 0;
-        // ---- pass 1: all sums once (id == table index when every class is complete); the table loads of four
-        // TEPs are issued together (the loop is latency-bound: one L2 round trip per trip otherwise)
+        // ---- ONE pass: all sums once (id == table index when every class is complete) into the cache, and their
+        // histogram over the a-priori range [lo, |y'_0| + |y'_1| + |y'_2|]; the table loads of four TEPs are issued
+        // together (the loop is latency-bound: one L2 round trip per trip otherwise)
+        const float mn = lo > 0.0f ? lo : 0.0f;
+        const float mx = P.order > 2 ? (L.w[0] + L.w[1]) + L.w[2] : L.w[0] + L.w[1];
+        const float scale = (float)kPbBins / (mx - mn);
+        for (int b = tid; b <= kPbBins; b += NT) { if (b < kPbBins) B.hist[b] = 0; B.binoff[b] = 0; }
+        __syncthreads();
         int cnt = 0;
-        float mn = __builtin_inff(), mx = -1.0f;
         for (int i = tid; i < nall; i += 4 * NT) {
             uchar4 t4[4];
 #pragma unroll
@@ -904,11 +909,14 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
                     if (t4[u].w > 1) s = s + L.w[t4[u].y];
                     if (t4[u].w > 2) s = s + L.w[t4[u].z];
                     cache[iu] = s;
-                    if (s > lo) { ++cnt; mn = __builtin_fminf(mn, s); mx = __builtin_fmaxf(mx, s); }
+                    if (s > lo) { ++cnt; atomicAdd(&B.hist[(int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1))], 1); }
                 }
             }
         }
-        pb_reduce3(B, cnt, mn, mx, lane, wave);
+        {
+            float d0f = 0.0f, d1f = 0.0f;
+            pb_reduce3(B, cnt, d0f, d1f, lane, wave);
+        }
         PB_STAMP(kProfFill);
         if (cnt > 0 && cnt <= CAP) {   // one chunk
             if (tid == 0) B.nkeys = 0;
@@ -921,21 +929,9 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
             PB_STAMP(kProfGather);
             state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, B.nkeys, tid, stop, ntep);
         } else if (cnt > CAP) {
-            const float scale = (float)kPbBins / (mx - mn);
             if (!(mn < mx) || !(scale < 3.0e38f)) state = 2;
             else {
-                // ---- pass 2: histogram; offsets by an exclusive scan over the bins
-                for (int b = tid; b <= kPbBins; b += NT) { if (b < kPbBins) B.hist[b] = 0; B.binoff[b] = 0; }
-                __syncthreads();
-                for (int i = tid; i < nall; i += 4 * NT) {
-                    float s4[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) s4[u] = i + u * NT < nall ? cache[i + u * NT] : -1.0f;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (s4[u] > lo) atomicAdd(&B.hist[(int)__builtin_fminf((s4[u] - mn) * scale, (float)(kPbBins - 1))], 1);
-                }
-                __syncthreads();
+                // ---- offsets of the bins by an exclusive scan
                 {
                     constexpr int PERB = (kPbBins + NT - 1) / NT;
                     int local = 0;
@@ -952,8 +948,6 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
                         if (b < kPbBins) { B.binoff[b] = run; run += B.hist[b]; }
                     }
                     if (tid == NT - 1) B.binoff[kPbBins] = run;
-                    __syncthreads();
-                    for (int b = tid; b < kPbBins; b += NT) B.hist[b] = 0;    // now the fill counters of the bins
                     __syncthreads();
                 }
                 PB_STAMP(kProfHist);
