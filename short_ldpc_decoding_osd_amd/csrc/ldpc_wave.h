@@ -69,6 +69,26 @@ __device__ __forceinline__ int wave_min_i32(int x)
     { const int ID = 0x7FFFFFFF; LDPC_WAVE_REDUCE(v, op_min_i) }
     return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ int op_max_i(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int wave_max_i32(int x)
+{
+    int v = x;
+    { const int ID = (int)0x80000000; LDPC_WAVE_REDUCE(v, op_max_i) }
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// inclusive prefix sum over the lanes (lane l gets x_0 + ... + x_l): row_shr DPP steps inside a row of 16, then the
+// row totals by row_bcast:15 / row_bcast:31
+__device__ __forceinline__ int wave_incl_add_dpp(int x)
+{
+    int v = x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
 // lane that holds the smallest (value, index) pair; ties on value go to the lower index
 __device__ __forceinline__ int wave_argmin_lane(float s, int idx)
 {
