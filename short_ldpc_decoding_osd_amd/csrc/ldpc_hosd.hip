@@ -17,14 +17,11 @@
 namespace ldpc {
 
 struct __attribute__((aligned(16))) HFrontLds {
-    int abits[128];            // |order_llr| as integer keys
+    RankLds rank;              // reliability sort (bucket_ranks, ldpc_wave.h)
     u64 colbuf[64];            // M columns in updated MRB order, bit = physical row
     unsigned mask[4];          // which sorted positions ended up in the MRB
     unsigned char lri[128];    // sorted position -> original bit
 };
-
-// r += (a > k): ascending ranks
-__device__ __forceinline__ void rank_lt(int &r, int a, int k) { rank_gt(r, k, a); }
 
 __global__ __launch_bounds__(256) void hosd_front_kernel(const float *__restrict__ x, long long F,
                                                          const u64 *__restrict__ Hcols,
@@ -39,33 +36,12 @@ __global__ __launch_bounds__(256) void hosd_front_kernel(const float *__restrict
 
     for (long long f = wave; f < F; f += (long long)gridDim.x * 4) {
         // ---- mag_input_gen (:25-28): rank in ascending |x|, ties -> lower index ------------
-        const int a1 = __float_as_int(x[f * 128 + lane]) & 0x7FFFFFFF;
-        const int a2 = __float_as_int(x[f * 128 + 64 + lane]) & 0x7FFFFFFF;
-        L.abits[lane] = a1;
-        L.abits[lane + 64] = a2;
-        wave_fence();
-        int r1 = 0, r2 = 0;
-#pragma unroll 8
-        for (int u4 = 0; u4 < 32; ++u4) {   // strict compares only; exact ties are repaired below
-            const int4 kq = *reinterpret_cast<const int4 *>(&L.abits[u4 * 4]);
-            rank_lt(r1, a1, kq.x); rank_lt(r2, a2, kq.x);
-            rank_lt(r1, a1, kq.y); rank_lt(r2, a2, kq.y);
-            rank_lt(r1, a1, kq.z); rank_lt(r2, a2, kq.z);
-            rank_lt(r1, a1, kq.w); rank_lt(r2, a2, kq.w);
-        }
-        L.lri[r1] = (unsigned char)lane;
-        L.lri[r2] = (unsigned char)(lane + 64);
-        wave_fence();
-        if (__ballot(L.lri[r1] != lane || L.lri[r2] != lane + 64)) {
-            wave_fence();
-            r1 = 0; r2 = 0;
-            for (int u = 0; u < 128; ++u) {   // "u before v" <=> a_u < a_v or (a_u == a_v and u < v)
-                const int ku = L.abits[u];
-                r1 += (ku < a1) || (ku == a1 && u < lane);
-                r2 += (ku < a2) || (ku == a2 && u < lane + 64);
-            }
-        }
-        wave_fence();
+        // ascending order of (|x| bits, index) = descending order of the complemented key, buckets mirrored
+        const unsigned a1 = __float_as_uint(x[f * 128 + lane]) & 0x7FFFFFFFu, a2 = __float_as_uint(x[f * 128 + 64 + lane]) & 0x7FFFFFFFu;
+        const float bs = bucket_scale(a1, a2);
+        int r1, r2;
+        bucket_ranks(L.rank, ~(((u64)a1 << 32) | (unsigned)lane), ~(((u64)a2 << 32) | (unsigned)(lane + 64)), 63 - bucket_of(a1, bs),
+                     63 - bucket_of(a2, bs), lane, r1, r2);
         L.lri[r1] = (unsigned char)lane;
         L.lri[r2] = (unsigned char)(lane + 64);
         if (lane < 4) L.mask[lane] = 0;

@@ -66,9 +66,7 @@ __global__ __launch_bounds__(256) void osd_ge_kernel(const u64 *__restrict__ row
 // OSD front end
 // ---------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) FrontLds {
-    u64 bk[192];             // the 128 sort keys grouped by bucket (descending), then 64 zero entries (never "before me")
-    int hist[64], cur[64];   // bucket counts / placement cursors
-    int base[64];            // number of keys in higher buckets
+    RankLds rank;            // reliability sort (bucket_ranks, ldpc_wave.h)
     u64 colbuf[64];          // parity columns in primed order
     unsigned mask[4];        // 128-bit membership mask of the MRB indices
     unsigned char pi1[128];  // sorted position -> original bit
@@ -88,34 +86,15 @@ __device__ __forceinline__ FrontResult front_device(FrontLds &L, const float *__
                                                     const u64 *__restrict__ Gcols, int lane)
 {
     // ---- reliability sort: rank of each |y| in descending order, ties -> lower index ------
-    // Sort key = (|y| bits, 127 - index) as one 64-bit integer: "u before v" <=> key_u > key_v.  The 128 keys are
-    // grouped into 64 value buckets (bucket = trunc(16 min(|y|, 3.99)), monotone in the key; a NaN lands in the top
-    // bucket like its bit pattern demands), the buckets laid out in descending order, and every key then counts the
-    // keys of ITS OWN bucket that sort before it: ~4 mates (12 in the fullest bucket) instead of all 128 -- the
-    // round-1 form spent 512 of the kernel's 1636 vector instructions on 256 compare + add-carry pairs per lane.
-    // (Entries past a bucket's end belong to lower buckets, i.e. smaller keys, so the count may run on to the wave's
-    // largest bucket size without a mask; 64 zero entries pad the array.)
-    const float v1 = y[src * 128 + lane], v2 = y[src * 128 + 64 + lane];
-    const unsigned a1 = __float_as_uint(v1) & 0x7FFFFFFFu, a2 = __float_as_uint(v2) & 0x7FFFFFFFu;
-    const u64 k1 = ((u64)a1 << 32) | (unsigned)(127 - lane), k2 = ((u64)a2 << 32) | (unsigned)(63 - lane);
-    const int b1 = (int)(__builtin_fminf(__uint_as_float(a1), 3.99f) * 16.0f), b2 = (int)(__builtin_fminf(__uint_as_float(a2), 3.99f) * 16.0f);
-    L.hist[lane] = 0; L.cur[lane] = 0; L.bk[128 + lane] = 0ull;
-    if (lane < 4) L.mask[lane] = 0;
-    wave_fence();
-    atomicAdd(&L.hist[b1], 1); atomicAdd(&L.hist[b2], 1);
-    wave_fence();
-    const int h = L.hist[lane];
-    L.base[lane] = 128 - wave_incl_add_dpp(h);                 // keys in the buckets above mine
-    const int nmax = wave_max_i32(h);
-    wave_fence();
-    const int s1 = L.base[b1], s2 = L.base[b2];
-    L.bk[s1 + atomicAdd(&L.cur[b1], 1)] = k1;
-    L.bk[s2 + atomicAdd(&L.cur[b2], 1)] = k2;
-    wave_fence();
-    int r1 = s1, r2 = s2;
-    for (int jj = 0; jj < nmax; ++jj) { r1 += L.bk[s1 + jj] > k1; r2 += L.bk[s2 + jj] > k2; }
+    // sort key = (|y| bits, 127 - index) as one 64-bit integer: "u before v" <=> key_u > key_v (bucket_ranks)
+    const unsigned a1 = __float_as_uint(y[src * 128 + lane]) & 0x7FFFFFFFu, a2 = __float_as_uint(y[src * 128 + 64 + lane]) & 0x7FFFFFFFu;
+    const float bs = bucket_scale(a1, a2);
+    int r1, r2;
+    bucket_ranks(L.rank, ((u64)a1 << 32) | (unsigned)(127 - lane), ((u64)a2 << 32) | (unsigned)(63 - lane), bucket_of(a1, bs),
+                 bucket_of(a2, bs), lane, r1, r2);
     L.pi1[r1] = (unsigned char)lane;
     L.pi1[r2] = (unsigned char)(lane + 64);
+    if (lane < 4) L.mask[lane] = 0;
     wave_fence();
     // ---- G with columns in sorted order, column-major ------------------------------------
     u64 C1 = Gcols[L.pi1[lane]];

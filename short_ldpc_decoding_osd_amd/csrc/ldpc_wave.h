@@ -231,6 +231,47 @@ __device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1,
     return deficient ? -1 : nsw;
 }
 
+// ---------------------------------------------------------------------------------------
+// Rank sort of 128 distinct 64-bit keys (two per lane) in DESCENDING order, one wavefront.
+// The keys are grouped into 64 value buckets (any bucket function that is monotone in the key), the buckets laid
+// out in descending order, and every key counts the keys of ITS OWN bucket that sort before it: ~4 mates (a dozen
+// in the fullest bucket) instead of all 128 -- the all-pairs form spent 512 vector instructions on 256 compare +
+// add-carry pairs per lane.  Entries past a bucket's end belong to lower buckets, i.e. smaller keys, so the count
+// may run on to the wave's largest bucket size without a mask; 64 zero entries pad the array.
+// ---------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) RankLds {
+    u64 bk[192];             // the keys grouped by bucket (descending), then 64 zero entries (never "before me")
+    int hist[64], cur[64];   // bucket counts / placement cursors
+    int base[64];            // number of keys in higher buckets
+};
+
+// bucket of a magnitude (given as its bit pattern) on a linear scale up to the frame's largest magnitude; monotone in
+// the bits for every input (a NaN lands in the top bucket, as its bit pattern demands)
+__device__ __forceinline__ float bucket_scale(unsigned a1, unsigned a2)
+{
+    const int m = wave_max_i32((int)(a1 > a2 ? a1 : a2));
+    return 63.5f / __int_as_float(m);
+}
+__device__ __forceinline__ int bucket_of(unsigned a, float scale) { return (int)__builtin_fminf(__uint_as_float(a) * scale, 63.0f); }
+
+__device__ __forceinline__ void bucket_ranks(RankLds &R, u64 k1, u64 k2, int b1, int b2, int lane, int &r1, int &r2)
+{
+    R.hist[lane] = 0; R.cur[lane] = 0; R.bk[128 + lane] = 0ull;
+    wave_fence();
+    atomicAdd(&R.hist[b1], 1); atomicAdd(&R.hist[b2], 1);
+    wave_fence();
+    const int h = R.hist[lane];
+    R.base[lane] = 128 - wave_incl_add_dpp(h);                 // keys in the buckets above mine
+    const int nmax = wave_max_i32(h);
+    wave_fence();
+    const int s1 = R.base[b1], s2 = R.base[b2];
+    R.bk[s1 + atomicAdd(&R.cur[b1], 1)] = k1;
+    R.bk[s2 + atomicAdd(&R.cur[b2], 1)] = k2;
+    wave_fence();
+    r1 = s1; r2 = s2;
+    for (int jj = 0; jj < nmax; ++jj) { r1 += R.bk[s1 + jj] > k1; r2 += R.bk[s2 + jj] > k2; }
+}
+
 // r += (k > a) as v_cmp_gt_i32 + v_addc through VCC (both 4-byte encodings)
 __device__ __forceinline__ void rank_gt(int &r, int a, int k)
 {

@@ -65,6 +65,10 @@ def test_front_and_search_match_oracle(dec, np_code, blocks):
     x[3, 10] = x[3, 77] = 0.0                                   # exact ties incl. zeros
     x[4, :] = np.float32(0.5) * np.sign(x[4, :])                # every key equal
     y[5, 20] = 0.0                                              # zero weight in the metric
+    x[6] *= np.float32(40.0)                                    # other scalings of the ordering values
+    x[7] *= np.float32(1e-3)
+    x[8, 77] = np.float32(1e30)                                 # an outlier: every other value in one sort bucket
+    x[9, :] = 0.0
     teps = np.concatenate([_tab(E) for E in blocks])
     off = np.insert(np.cumsum([len(E) for E in blocks]), 0, 0).astype(np.int32)
     front = dec.hosd_front(to_dev(x, dec))

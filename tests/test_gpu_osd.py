@@ -75,6 +75,13 @@ def test_front_end_ties_and_zeros(dec):
     y[3] = np.round(y[3] * 4) / 4            # many duplicates
     y[4, 10] = -y[4, 20]
     y[5] = -0.0
+    # other input scalings (the sort's value buckets scale with the frame's largest magnitude)
+    y[6] *= 40.0
+    y[7] *= 1e-3
+    y[8, 77] = 1e30                          # one outlier: every other value lands in one bucket
+    y[9, 5], y[9, 100] = np.inf, -np.inf
+    y[10] *= 1e-41                           # denormals
+    y[11, 3] = 3.0e38
     perm, parity, ns = dec.osd_front(to_dev(y, dec))
     torch.cuda.synchronize()
     perm_o, par_o, ns_o = _front_oracle(dec, y)
