@@ -731,7 +731,7 @@ void osd_ctx_release(ldpc_ctx *ctx)
         for (auto &kv : st->ws) {
             (void)hipFree(kv.second.d_perm); (void)hipFree(kv.second.d_parity);
             (void)hipFree(kv.second.d_pb_ctl); (void)hipFree(kv.second.d_pb_list); (void)hipFree(kv.second.d_pb_spill);
-            (void)hipFree(kv.second.d_pb_cache); (void)hipFree(kv.second.d_pb_carry); (void)hipFree(kv.second.d_pb_prep);
+            (void)hipFree(kv.second.d_pb_carry); (void)hipFree(kv.second.d_pb_prep);
         }
         (void)hipFree(st->d_tep_fs);
         (void)hipFree(st->d_base2);

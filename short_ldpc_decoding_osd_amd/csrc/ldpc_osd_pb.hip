@@ -22,11 +22,13 @@
 //   pb_singles_kernel  one frame per wavefront: the pop sequence starts with the weight-1 TEPs {63}, {62}, ...
 //                      while |y'_p| < |y'_62| + |y'_63| (the smallest weight-2 sum); one TEP per lane.  About
 //                      half of the frames stop here at 2.5 dB; the others are appended to list A.
-//   pb_block_kernel    one frame of list A per workgroup, restarted from its first TEP: chunks chosen by value
-//                      thresholds (|y'_0|, then +inf) with per-weight-class candidate pruning, split by a
-//                      histogram when a threshold holds more than CAP TEPs; bitonic sort in LDS; exact tie
-//                      repair; parallel evaluation.  Frames whose sums tie massively (quantised inputs) are
-//                      appended to list B.
+//   pb_block_kernel    one frame of list A per 256-thread workgroup, restarted from its first TEP: two chunks of ~768
+//                      TEPs (capacity 1024), each = the members of a sum range generated directly from the sorted
+//                      reliabilities (PbItems: no table pass), its upper bound chosen by pb_pick_bound; bucket rank sort
+//                      in LDS; exact tie repair; parallel evaluation; sequential rules by prefix scans.  96 % of the
+//                      frames stop here; the rest go to list C with their search state, massive ties to list B.
+//   pb_heavy_kernel    one frame of list C per 1024-thread workgroup: chunks of ~3072 TEPs (capacity 4096) until a
+//                      rule fires or all N_max TEPs are visited.
 //   pb_seq_kernel      the literal list replay (round-1 kernel) for list B.
 #include <math.h>
 #include <stdio.h>
@@ -79,6 +81,7 @@ struct __attribute__((aligned(16))) PbLds {
 
 struct PbParams {
     int order, nmax;
+    int t1, t2, t3;              // chunk targets: stage A first / second chunk, stage B
     float c4;
     long long cmin_off;          // offset of the spilled chunk minima inside a wave's global area
 };
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256) void pb_singles_kernel(const float *__restrict
 // ---------------------------------------------------------------------------------------
 // stage 2: one frame per workgroup, sorted chunks
 // ---------------------------------------------------------------------------------------
-constexpr int kPbBins = 1024, kPbMaxTie = 16;
+constexpr int kPbMaxTie = 16;
 
 template <int NT, int CAP>
 struct __attribute__((aligned(16))) PbBlockLds {
@@ -402,8 +405,6 @@ struct __attribute__((aligned(16))) PbBlockLds {
     u64 gath[CAP];          // the chunk as gathered: (sum bits << 32) | table id; after the sort: the costs (float[CAP])
     u64 keys[CAP];          // the chunk in visit order
     int bucket[CAP];        // bucket sort: counts, then cursors
-    int hist[kPbBins];
-    int binoff[kPbBins + 1];
     float red_f[2][NT / 64];
     int red_i[2][NT / 64];
     PbFrame fr;
@@ -422,27 +423,215 @@ enum { kProfSetup = 0, kProfPassA, kProfHist, kProfGather, kProfSort, kProfTie, 
        kProfScatter, kProfFinish, kProfFrames, kProfChunks };
 #define PB_STAMP(k) do { if constexpr (PROF) { if (tid == 0) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); B.prof[k] += now__ - B.prof_last; B.prof_last = now__; } } } while (0)
 
-// candidate prefix lengths of the three weight classes for the sum bound `hi` (all TEPs with sum <= hi have
-// their smallest position in the prefix; the slack terms cover the roundings of the float32 sums)
-__device__ __forceinline__ void pb_candidates(const SearchLds &L, float hi, int order, int lane, int &n1, int &n2, int &n3)
+// ---------------------------------------------------------------------------------------
+// Direct enumeration of a sum range.  The positions are sorted by reliability (w[0] >= w[1] >= ...) and float addition is
+// monotone, so with the other positions fixed the sum of a TEP is non-increasing in its LAST position m.  The TEPs are
+// therefore 2080 "items" -- all singles {m}; the pairs {i, m} of one i; the triples {i, j, m} of one (i, j) -- inside each
+// of which the members with lo < sum <= T are a contiguous run [a, e) of m, found by a 7-step binary search in LDS.
+// A thread owns 3 (1024 threads) or 9 (256 threads) items; counting a range is one search per item and a block scan, a
+// chunk is written from the runs.  The cost follows the items and the chunk, not the 43 744-entry table, nothing is read
+// from global memory, and the upper bound of a chunk can be ANY value -- the search is exact for every choice -- which
+// pb_pick_bound uses to size the chunks.
+//   item 0: singles;  items 1..63: pairs of i = item - 1;  items 64..2079: triples of the pair tab[item]
+// (a wavefront-wide visit per item with lane = m was measured too: 30 instructions per item at ~6 % useful lanes for the
+//  early chunks, 4-10x the time of the searches; a 1024-bin histogram of all sums costs as much as the table pass it
+//  replaced)
+// ---------------------------------------------------------------------------------------
+template <int NT>
+struct PbItems {
+    static constexpr int IPT = (kPbTriples0 + NT - 1) / NT;
+    // frame-independent (set once per workgroup), packed: bits 0-6 base + 1 (the last position runs over (base, 63];
+    // singles: base = -1, an empty item: 63), bits 7-13 first fixed position + 1 (0: none), bit 14 triple item,
+    // bits 16-31 idb (table id of member m = idb + m; singles: 63 - m)
+    unsigned st[IPT];
+    // per frame
+    float sb[IPT];    // sum of the fixed positions
+    unsigned ea[IPT]; // e | a << 8: members already visited (sum <= lo) [e, 64); members of the chunk being sized [a, e)
+    __device__ __forceinline__ int base(int q) const { return (int)(st[q] & 127u) - 1; }
+    __device__ __forceinline__ int e(int q) const { return (int)(ea[q] & 255u); }
+    __device__ __forceinline__ int a(int q) const { return (int)(ea[q] >> 8); }
+};
+
+// first m in [lo, hi) with sb + w[m] <= T (hi if none), for three items of the thread at once: the seven LDS reads of an
+// item depend on each other, those of different items do not
+template <int NT, int G>
+__device__ __forceinline__ void pb_first_le3(const PbItems<NT> &I, const float *w, float T, int (&lo)[PbItems<NT>::IPT], int (&hi)[PbItems<NT>::IPT])
 {
-    const float wl = L.w[lane];
-    const float w63 = L.w[63], w6263 = L.w[62] + L.w[63];
-    const bool inf = !(hi < __builtin_inff());
-    const float h2 = (hi - w63) + hi * 9.5367431640625e-7f;       // 2^-20
-    const float h3 = (hi - w6263) + hi * 1.9073486328125e-6f;     // 2^-19
-    const u64 m1 = __ballot(inf || wl <= hi), m2 = __ballot(inf || wl <= h2), m3 = __ballot(inf || wl <= h3);
-    const int c1 = m1 ? 64 - __builtin_ctzll(m1) : 0, c2 = m2 ? 64 - __builtin_ctzll(m2) : 0, c3 = m3 ? 64 - __builtin_ctzll(m3) : 0;
-    n1 = c1;
-    n2 = order > 1 ? c2 * (c2 - 1) / 2 : 0;
-    n3 = order > 2 ? c3 * (c3 - 1) * (c3 - 2) / 6 : 0;
+    constexpr int Q0 = 3 * G, Q1 = Q0 + 3 < PbItems<NT>::IPT ? Q0 + 3 : PbItems<NT>::IPT;
+#pragma unroll
+    for (int it = 0; it < 7; ++it)
+#pragma unroll
+        for (int q = Q0; q < Q1; ++q) {
+            const int mid = (lo[q] + hi[q]) >> 1;
+            const bool act = lo[q] < hi[q], ok = I.sb[q] + w[mid < 63 ? mid : 63] <= T;
+            hi[q] = (act && ok) ? mid : hi[q];
+            lo[q] = (act && !ok) ? mid + 1 : lo[q];
+        }
 }
 
-__device__ __forceinline__ void pb_cand(const uchar4 *__restrict__ tab, const float *w, int i, int n1, int n2, int &id, float &sum)
+// The items are laid out by DESCENDING first position, so those that can hold a member with sum <= T -- their smallest
+// sum, (w_i + w_62) + w_63 for the triples of i, is monotone in i -- are a prefix of the item list; a thread's item
+// slots q >= the returned count hold no such item for any thread (uniform), and are skipped as a whole.
+template <int NT>
+__device__ __forceinline__ int pb_items_slots(const float *w, float T, int order, int lane)
 {
-    if (i < n1) { id = i; sum = w[63 - i]; }
-    else if (i < n1 + n2) { id = kPbPairs0 + (i - n1); const uchar4 t = tab[id]; sum = w[t.x] + w[t.y]; }
-    else { id = kPbTriples0 + (i - n1 - n2); const uchar4 t = tab[id]; sum = (w[t.x] + w[t.y]) + w[t.z]; }
+    const u64 ok = __ballot((w[lane] + w[62]) + w[63] <= T);          // first positions i whose triples can reach below T
+    const int imin = ok ? (int)__builtin_ctzll(ok) : 64;
+    const int r = 64 - imin;                                          // positions >= imin
+    const int items = order > 2 ? kPbPairs0 + r * (r - 1) / 2 : kPbPairs0;
+    const int slots = (items + NT - 1) / NT;
+    return slots < PbItems<NT>::IPT ? slots : PbItems<NT>::IPT;
+}
+
+template <int NT>
+__device__ __forceinline__ void pb_first_le(const PbItems<NT> &I, const float *w, float T, int slots, int (&lo)[PbItems<NT>::IPT], int (&hi)[PbItems<NT>::IPT])
+{
+    pb_first_le3<NT, 0>(I, w, T, lo, hi);
+    if constexpr (PbItems<NT>::IPT > 3) { if (slots > 3) pb_first_le3<NT, 1>(I, w, T, lo, hi); }
+    if constexpr (PbItems<NT>::IPT > 6) { if (slots > 6) pb_first_le3<NT, 2>(I, w, T, lo, hi); }
+    static_assert(PbItems<NT>::IPT <= 9, "item groups");
+}
+
+template <int NT>
+__device__ __forceinline__ void pb_items_static(PbItems<NT> &I, const uchar4 *__restrict__ tab, int order, int tid)
+{
+    const int nitems = order > 2 ? kPbTriples0 : (order > 1 ? kPbPairs0 : 1);
+#pragma unroll
+    for (int q = 0; q < PbItems<NT>::IPT; ++q) {
+        const int it = tid + q * NT;
+        I.st[q] = 64u;                                              // (an empty item: base = 63)
+        if (it == 0) I.st[q] = 0u;
+        else if (it < kPbPairs0 && it < nitems) {
+            const int i = it - 1, m = 63 - i;
+            I.st[q] = (unsigned)(i + 1) | ((unsigned)(i + 1) << 7) | ((unsigned)(kPbPairs0 + m * (m - 1) / 2 - (i + 1)) << 16);
+        } else if (it < nitems) {
+            const uchar4 t = tab[it];
+            const int i = t.x, j = t.y, m = 63 - i, r = 64 - j;
+            I.st[q] = (unsigned)(j + 1) | ((unsigned)(i + 1) << 7) | (1u << 14) |
+                      ((unsigned)(kPbTriples0 + m * (m - 1) * (m - 2) / 6 + m * (m - 1) / 2 - r * (r - 1) / 2 - (j + 1)) << 16);
+        }
+    }
+}
+
+// per-frame part: fixed sums, and the members with sum <= lo (already visited) cut off
+template <int NT>
+__device__ __forceinline__ void pb_items_frame(PbItems<NT> &I, const float *w, float lo)
+{
+    constexpr int IPT = PbItems<NT>::IPT;
+    int l[IPT], h[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+        const int i1 = (int)((I.st[q] >> 7) & 127u);     // first fixed position + 1
+        float sb = i1 ? w[i1 - 1] : 0.0f;
+        if (I.st[q] & (1u << 14)) sb = sb + w[I.base(q)];
+        I.sb[q] = sb;
+        l[q] = I.base(q) + 1; h[q] = 64;
+    }
+    if (!(lo < 0.0f)) pb_first_le(I, w, lo, IPT, l, h);
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) { const int e = lo < 0.0f ? 64 : l[q]; I.ea[q] = (unsigned)e | ((unsigned)e << 8); }
+}
+
+// a := start of the members with sum <= T (never past e); returns this thread's number of members in [a, e)
+template <int NT>
+__device__ __forceinline__ int pb_items_bound(PbItems<NT> &I, const float *w, float T, int order, int lane)
+{
+    constexpr int IPT = PbItems<NT>::IPT;
+    int l[IPT], h[IPT];
+    const int slots = pb_items_slots<NT>(w, T, order, lane);
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) { h[q] = I.e(q); l[q] = q < slots ? I.base(q) + 1 : h[q]; l[q] = l[q] < h[q] ? l[q] : h[q]; }
+    pb_first_le(I, w, T, slots, l, h);
+    int local = 0;
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) { I.ea[q] = (I.ea[q] & 255u) | ((unsigned)l[q] << 8); local += I.e(q) - l[q]; }
+    return local;
+}
+
+// exclusive prefix of `local` over the threads of the workgroup and the total (one barrier; `slot` alternates between
+// successive calls so that a slow reader of the previous call is never overwritten)
+template <int NT, int CAP>
+__device__ __forceinline__ int pb_block_scan(PbBlockLds<NT, CAP> &B, int local, int lane, int wave, int slot, int &total)
+{
+    const int incl = wave_incl_add(local, lane);
+    if (lane == 63) B.red_i[slot][wave] = incl;
+    __syncthreads();
+    int run = incl - local;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { const int v = B.red_i[slot][w]; total += v; run += w < wave ? v : 0; }
+    return run;
+}
+
+// the members [a, e) of my items as chunk keys from slot `run` on; then the range is consumed (e := a)
+template <int NT, int CAP>
+__device__ __forceinline__ void pb_items_write(PbBlockLds<NT, CAP> &B, PbItems<NT> &I, const float *w, int run)
+{
+#pragma unroll
+    for (int q = 0; q < PbItems<NT>::IPT; ++q) {
+        const int a = I.a(q), e = I.e(q), idb = (int)(I.st[q] >> 16);
+        const bool singles = (I.st[q] & 127u) == 0u;
+        for (int m = a; m < e; ++m)
+            B.gath[run++] = ((u64)__float_as_uint(I.sb[q] + w[m]) << 32) | (unsigned)(singles ? 63 - m : idb + m);
+        I.ea[q] = (unsigned)a | ((unsigned)a << 8);
+    }
+}
+
+// Typical bound of the N smallest sums in units of the smallest triple sum m3 = w61 + w62 + w63 (medians over decoding
+// failures at 2.5 dB; the ratio is scale-free and tight: +-6 % between the 10th and 90th percentile, where the count
+// changes like the ~6th power of the bound).  Only a first guess: pb_pick_bound corrects it with exact counts.
+__device__ __forceinline__ float pb_bound_guess(float n)
+{
+    const float l = __builtin_amdgcn_logf(n < 64.0f ? 64.0f : n);
+    const float x[8] = {8.0f, 9.0f, 10.0f, 11.0f, 12.0f, 13.0f, 14.2877f, 15.4168f};     // log2 of 256 ... 20000, 43744
+    const float g[8] = {0.80f, 0.89f, 1.02f, 1.14f, 1.23f, 1.33f, 1.52f, 2.2f};
+    if (l <= x[0]) return g[0] * __builtin_amdgcn_exp2f((l - x[0]) / 6.0f);
+    float r = g[7];
+#pragma unroll
+    for (int k = 6; k >= 0; --k) if (l <= x[k + 1]) r = g[k] + (g[k + 1] - g[k]) * (l - x[k]) / (x[k + 1] - x[k]);
+    return r;
+}
+
+// Upper bound T of the next chunk: 0 < #(lo < sum <= T) <= CAP, aimed at `target` members.  First guess from
+// pb_bound_guess (or, past the first chunk, from the growth exponent between the last two bounds), then corrected with the
+// exact counts it meets (secant step on log N over log T), bisected when that stops helping.  Every wavefront runs the
+// same arithmetic on the same values.  Returns the count in n (-1: the range cannot be split -- massively equal sums --
+// and the frame goes to the list replay) and the write offset of this wavefront's share in wbase.
+template <int NT, int CAP>
+__device__ __forceinline__ float pb_pick_bound(PbBlockLds<NT, CAP> &B, PbItems<NT> &I, const float *w, int order, float lo, int done, int nall,
+                                               int target, int lane, int wave, int &n, int &run)
+{
+    const float inf = __builtin_inff();
+    const float m3 = (w[61] + w[62]) + w[63];
+    const float want = (float)(done + target);
+    float Tl = lo, Th = inf;
+    float T = nall - done <= CAP ? inf : m3 * pb_bound_guess(want);
+    if (!(T > lo)) T = lo > 0.0f ? lo * 1.05f : w[0];
+    float tp = lo, np_ = (float)done;        // last point with a known count (lo > 0 and done > 0: usable for the exponent)
+    for (int it = 0;; ++it) {
+        int c;
+        run = pb_block_scan(B, pb_items_bound(I, w, T, order, lane), lane, wave, it & 1, c);
+        if (c > 0 && c <= CAP && (!(T < inf) || 5 * c >= 2 * target || it >= 2)) { n = c; return T; }
+        if (it >= 40 || !(T < inf)) break;
+        float Tn;
+        if (c == 0) { Tl = T; Tn = T * 1.1f; }
+        else {
+            if (c > CAP) Th = T;
+            const float tot = (float)(done + c);
+            float p = 6.0f;
+            if (tp > 0.0f && np_ > 0.0f && tot != np_ && T != tp) {
+                const float pe = (__builtin_amdgcn_logf(tot) - __builtin_amdgcn_logf(np_)) / (__builtin_amdgcn_logf(T) - __builtin_amdgcn_logf(tp));
+                if (pe > 1.5f && pe < 20.0f) p = pe;
+            }
+            tp = T; np_ = tot;
+            Tn = T * __builtin_amdgcn_exp2f((__builtin_amdgcn_logf(want) - __builtin_amdgcn_logf(tot)) / p);
+        }
+        if (it >= 6 || !(Tn > Tl) || !(Tn < Th)) Tn = Th < inf ? Tl + (Th - Tl) * 0.5f : T * 1.2f;
+        if (!(Tn > Tl) || !(Tn < Th)) break;
+        T = Tn;
+    }
+    n = -1;
+    return lo;
 }
 
 // block reductions of (count, min, max); every thread gets the results
@@ -461,43 +650,6 @@ __device__ __forceinline__ void pb_reduce3(PbBlockLds<NT, CAP> &B, int &cnt, flo
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) { cnt += B.red_i[0][w]; mn = __builtin_fminf(mn, B.red_f[0][w]); mx = __builtin_fmaxf(mx, B.red_f[1][w]); }
     __syncthreads();
-}
-
-// Largest bin b in (bprev, kPbBins) such that hist[bprev+1 .. b] holds <= CAP entries (-1 if even the first bin
-// does not fit), and that count; every thread gets both.
-template <int NT, int CAP>
-__device__ __forceinline__ int pb_pick_bins(PbBlockLds<NT, CAP> &B, int bprev, int &count, int tid, int lane, int wave)
-{
-    constexpr int PERB = kPbBins / NT, W = NT / 64;
-    int local = 0;
-#pragma unroll
-    for (int q = 0; q < PERB; ++q) { const int b = tid * PERB + q; local += b > bprev ? B.hist[b] : 0; }
-    const int incl = wave_incl_add(local, lane);
-    if (lane == 63) B.red_i[0][wave] = incl;
-    __syncthreads();
-    int run = incl - local;
-    for (int w = 0; w < wave; ++w) run += B.red_i[0][w];
-    int mybest = -1, mycount = 0;
-#pragma unroll
-    for (int q = 0; q < PERB; ++q) {
-        const int b = tid * PERB + q;
-        run += b > bprev ? B.hist[b] : 0;
-        if (b > bprev && run <= CAP) { mybest = b; mycount = run; }
-    }
-    // arg-max on the bin index (counts are non-decreasing in the bin, so the count of the largest bin is the largest)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int t = __shfl_xor(mybest, off, 64), c = __shfl_xor(mycount, off, 64);
-        if (t > mybest) { mybest = t; mycount = c; }
-    }
-    if (lane == 0) { B.red_i[1][wave] = mybest; B.red_i[0][wave] = mycount; }
-    __syncthreads();
-    int bstar = -1;
-    count = 0;
-#pragma unroll
-    for (int w = 0; w < W; ++w) if (B.red_i[1][w] > bstar) { bstar = B.red_i[1][w]; count = B.red_i[0][w]; }
-    __syncthreads();
-    return bstar;
 }
 
 // The n gathered keys of one chunk (all TEPs of a sum range): sort into visit order, evaluate in parallel, apply
@@ -744,11 +896,10 @@ __device__ __forceinline__ SearchFrame pb_block_setup(PbBlockLds<NT, CAP> &B, co
     return S;
 }
 
-// Stage A of a frame of list A: the TEPs with sum <= |y'_0| (1e3 of them typically) as ONE chunk, candidates pruned
-// per weight class.  A frame on which no rule fires here -- or whose bound holds more than a chunk -- goes on to
-// list C with its search state (pb_heavy_kernel), massive ties to list B (list replay).
-template <int NT, int CAP, bool PROF>
-__global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ y, const int *__restrict__ index,
+// Stage A of a frame of list A: the first two chunks of the visit order.  A frame on which no rule fires here goes on
+// to list C with its search state (pb_heavy_kernel), massive ties to list B (list replay).
+template <int NT, int CAP, bool PROF, int MINW = 1>
+__global__ __launch_bounds__(NT, MINW) void pb_block_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                       const unsigned char *__restrict__ perm_in,
                                                       const u64 *__restrict__ parity_in, PbParams P,
                                                       const double *__restrict__ cdf_half,
@@ -762,7 +913,10 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
     SearchLds &L = B.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nlist = ctl[1];
+    const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);
     if (tid < 65) B.cdfH[tid] = cdf_half[tid];
+    PbItems<NT> I;
+    pb_items_static(I, tab, P.order, tid);
     if constexpr (PROF) { if (tid < 24) B.prof[tid] = 0; if (tid == 0) B.prof_last = __builtin_amdgcn_s_memtime(); }
 
     for (;;) {
@@ -786,33 +940,26 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
         if constexpr (PROF) { fstart = __builtin_amdgcn_s_memtime(); fchunks = B.prof[kProfChunks]; }
         const PbFrame Fr = B.fr;
         const u64 d0 = B.d0;
-        const float theta = L.w[0];
         int stop = 0, ntep = P.nmax, state = 0;   // state: 0 = searching, 1 = a rule fired, 2 = hand the frame to the list replay
 
-        {   // ONE pass over the pruned candidates counts the TEPs with sum <= |y'_0| and gathers them on the spot; if they
-            // do not fit one chunk the frame goes to stage B untouched (1024 threads, cached sums, one histogram: the
-            // eight latency-bound passes per chunk this took here made such a frame the 2.4 M-cycle tail of the launch)
-            int n1, n2, n3;
-            pb_candidates(L, theta, P.order, lane, n1, n2, n3);
-            const int total = n1 + n2 + n3;
-            if (tid == 0) B.nkeys = 0;
-            __syncthreads();
-            for (int i = tid; i < total; i += NT) {
-                int id; float s;
-                pb_cand(tab, L.w, i, n1, n2, id, s);
-                if (s <= theta) {
-                    const int slot = atomicAdd(&B.nkeys, 1);
-                    if (slot < CAP) B.gath[slot] = ((u64)__float_as_uint(s) << 32) | (unsigned)id;
-                }
-            }
+        // Two chunks of increasing sums here (aimed at ~512, then ~1536 TEPs: 88 % / 96 % of the frames that reach this
+        // kernel stop inside them); a frame that is still searching then goes to stage B with its state.
+        pb_items_frame(I, L.w, -1.0f);
+        float lo = -1.0f;
+        int done = 0;
+        for (int chunk = 0; chunk < 2 && state == 0 && done < nall; ++chunk) {
+            int n, run;
+            const float T = pb_pick_bound(B, I, L.w, P.order, lo, done, nall, chunk == 0 ? P.t1 : P.t2, lane, wave, n, run);
+            PB_STAMP(kProfHist);
+            if (n < 0) { state = 2; break; }
+            pb_items_write(B, I, L.w, run);
             __syncthreads();
             PB_STAMP(kProfPassA);
-            const int n = B.nkeys;
-            if (n <= CAP) {
-                if (n > 0) state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, tid, stop, ntep);
-                if (state == 0 && tid == 0) B.lo = theta;
-            }
+            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, tid, stop, ntep);
+            lo = T;
+            done += n;
         }
+        if (state == 0 && tid == 0) B.lo = lo;
         __syncthreads();
         if constexpr (PROF) {
             if (tid == 0) {
@@ -825,7 +972,7 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
             if (tid == 0) listB[atomicAdd(&ctl[3], 1)] = (int)f;
             continue;
         }
-        if (state == 0 && P.order > 1) {   // no rule fired below |y'_0|: the search goes on over ALL remaining TEPs
+        if (state == 0 && done < nall) {   // no rule fired so far: the search goes on over the remaining TEPs
             if (tid == 0) {
                 PbCarry c;
                 c.lo = B.lo; c.best = B.best; c.j = B.j; c.nlive = B.nlive; c.cmp = B.cmp; c.suc1 = B.suc1; c.suc2 = B.suc2;
@@ -843,17 +990,14 @@ __global__ __launch_bounds__(NT) void pb_block_kernel(const float *__restrict__ 
     if constexpr (PROF) { __syncthreads(); if (tid < 21) atomicAdd(&prof_out[tid], B.prof[tid]); else if (tid < 24) atomicMax(&prof_out[tid], B.prof[tid]); }
 }
 
-// Stage B of a frame of list C: every TEP with a sum above |y'_0|.  The 43 744 sums are computed once into a
-// per-workgroup global array (L2-resident, each thread re-reads what it wrote) and histogrammed (1024 bins over an
-// a-priori range) in the same pass; a chunk is then a run of whole bins, gathered by one streaming pass over the
-// cached sums.  A full scan is one pass over the TEP table plus ~11 chunks.
+// Stage B of a frame of list C: the visit order continues above the bound stage A reached, in chunks of up to 4096
+// TEPs, until a rule fires or the table is exhausted (a full scan of 43 744 TEPs is ~15 chunks).
 template <int NT, int CAP, bool PROF>
 __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                       const unsigned char *__restrict__ perm_in,
                                                       const u64 *__restrict__ parity_in, PbParams P,
                                                       const double *__restrict__ cdf_half,
-                                                      const uchar4 *__restrict__ tab, float *__restrict__ cache_all,
-                                                      int *__restrict__ ctl,
+                                                      const uchar4 *__restrict__ tab, int *__restrict__ ctl,
                                                       const int *__restrict__ listC, int *__restrict__ listB,
                                                       const PbCarry *__restrict__ carry, const PbPrep *__restrict__ prep, PbOut O,
                                                       unsigned long long *__restrict__ prof_out)
@@ -863,9 +1007,10 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
     SearchLds &L = B.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nlist = ctl[5];
-    float *cache = cache_all + (size_t)blockIdx.x * kPbTabSize;
     const int nall = P.order == 2 ? kPbTriples0 : kPbTabSize;
     if (tid < 65) B.cdfH[tid] = cdf_half[tid];
+    PbItems<NT> I;
+    pb_items_static(I, tab, P.order, tid);
     if constexpr (PROF) { if (tid < 24) B.prof[tid] = 0; if (tid == 0) B.prof_last = __builtin_amdgcn_s_memtime(); }
 
     for (;;) {
@@ -886,111 +1031,22 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
         PB_STAMP(kProfSetup);
         const PbFrame Fr = B.fr;
         const u64 d0 = B.d0;
-        const float lo = B.lo;    // = |y'_0|
         int stop = 0, ntep = P.nmax, state = 0;
-        // ---- ONE pass: all sums once (id == table index when every class is complete) into the cache, and their
-        // histogram over the a-priori range [lo, |y'_0| + |y'_1| + |y'_2|]; the table loads of four TEPs are issued
-        // together (the loop is latency-bound: one L2 round trip per trip otherwise)
-        const float mn = lo > 0.0f ? lo : 0.0f;
-        const float mx = P.order > 2 ? (L.w[0] + L.w[1]) + L.w[2] : L.w[0] + L.w[1];
-        const float scale = (float)kPbBins / (mx - mn);
-        for (int b = tid; b <= kPbBins; b += NT) { if (b < kPbBins) B.hist[b] = 0; B.binoff[b] = 0; }
-        __syncthreads();
-        int cnt = 0;
-        for (int i = tid; i < nall; i += 4 * NT) {
-            uchar4 t4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t4[u] = tab[i + u * NT < nall ? i + u * NT : 0];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int iu = i + u * NT;
-                if (iu < nall) {
-                    float s = L.w[t4[u].x];
-                    if (t4[u].w > 1) s = s + L.w[t4[u].y];
-                    if (t4[u].w > 2) s = s + L.w[t4[u].z];
-                    cache[iu] = s;
-                    if (s > lo) { ++cnt; atomicAdd(&B.hist[(int)__builtin_fminf((s - mn) * scale, (float)(kPbBins - 1))], 1); }
-                }
-            }
-        }
-        {
-            float d0f = 0.0f, d1f = 0.0f;
-            pb_reduce3(B, cnt, d0f, d1f, lane, wave);
-        }
-        PB_STAMP(kProfFill);
-        if (cnt > 0 && cnt <= CAP) {   // one chunk
-            if (tid == 0) B.nkeys = 0;
-            __syncthreads();
-            for (int i = tid; i < nall; i += NT) {
-                const float s = cache[i];
-                if (s > lo) B.gath[atomicAdd(&B.nkeys, 1)] = ((u64)__float_as_uint(s) << 32) | (unsigned)i;
-            }
+        // ---- chunks of increasing sums (aimed at 3/4 of the capacity) until a rule fires or the table is exhausted
+        float lo = B.lo;
+        int done = B.j;
+        pb_items_frame(I, L.w, lo);
+        while (state == 0 && done < nall) {
+            int n, run;
+            const float T = pb_pick_bound(B, I, L.w, P.order, lo, done, nall, P.t3, lane, wave, n, run);
+            PB_STAMP(kProfHist);
+            if (n < 0) { state = 2; break; }
+            pb_items_write(B, I, L.w, run);
             __syncthreads();
             PB_STAMP(kProfGather);
-            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, B.nkeys, tid, stop, ntep);
-        } else if (cnt > CAP) {
-            if (!(mn < mx) || !(scale < 3.0e38f)) state = 2;
-            else {
-                // ---- offsets of the bins by an exclusive scan
-                {
-                    constexpr int PERB = (kPbBins + NT - 1) / NT;
-                    int local = 0;
-#pragma unroll
-                    for (int q = 0; q < PERB; ++q) { const int b = tid * PERB + q; local += b < kPbBins ? B.hist[b] : 0; }
-                    const int incl = wave_incl_add(local, lane);
-                    if (lane == 63) B.red_i[0][wave] = incl;
-                    __syncthreads();
-                    int run = incl - local;
-                    for (int w = 0; w < wave; ++w) run += B.red_i[0][w];
-#pragma unroll
-                    for (int q = 0; q < PERB; ++q) {
-                        const int b = tid * PERB + q;
-                        if (b < kPbBins) { B.binoff[b] = run; run += B.hist[b]; }
-                    }
-                    if (tid == NT - 1) B.binoff[kPbBins] = run;
-                    __syncthreads();
-                }
-                PB_STAMP(kProfHist);
-                // ---- chunks: the longest run of whole bins that fits, gathered by one streaming pass over the cached sums
-                // (a counting sort of all 43 744 keys into a second global array was measured: its scattered 8-byte stores
-                //  cost as much as eleven such passes, and most frames stop after one or two chunks)
-                int bprev = -1;
-                while (state == 0 && bprev < kPbBins - 1) {
-                    const int base = B.binoff[bprev + 1];
-                    int mybest = -1;
-                    for (int b = tid; b < kPbBins; b += NT)
-                        if (b > bprev && B.binoff[b + 1] - base <= CAP) mybest = b > mybest ? b : mybest;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) { const int t = __shfl_xor(mybest, off, 64); mybest = t > mybest ? t : mybest; }
-                    if (lane == 0) B.red_i[1][wave] = mybest;
-                    if (tid == 0) B.nkeys = 0;
-                    __syncthreads();
-                    int bnext = -1;
-#pragma unroll
-                    for (int w = 0; w < W; ++w) bnext = B.red_i[1][w] > bnext ? B.red_i[1][w] : bnext;
-                    __syncthreads();
-                    if (bnext < 0) { state = 2; break; }       // one bin holds more than a chunk: massive ties
-                    const int n = B.binoff[bnext + 1] - base;
-                    if (n > 0) {
-                        for (int i = tid; i < nall; i += 4 * NT) {
-                            float s4[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) s4[u] = i + u * NT < nall ? cache[i + u * NT] : -1.0f;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (s4[u] > lo) {
-                                    const int bin = (int)__builtin_fminf((s4[u] - mn) * scale, (float)(kPbBins - 1));
-                                    if (bin > bprev && bin <= bnext)
-                                        B.gath[atomicAdd(&B.nkeys, 1)] = ((u64)__float_as_uint(s4[u]) << 32) | (unsigned)(i + u * NT);
-                                }
-                        }
-                        __syncthreads();
-                        PB_STAMP(kProfGather);
-                        state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, tid, stop, ntep);
-                    }
-                    bprev = bnext;
-                }
-            }
+            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, tid, stop, ntep);
+            lo = T;
+            done += n;
         }
         __syncthreads();
         if (state == 2) {
@@ -1217,8 +1273,6 @@ static int stream_ws_pb(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int64_t sp
         (void)hipFree(w.d_pb_list); w.d_pb_list = nullptr; w.pb_cap = 0;
         if (!w.d_pb_ctl && hipMalloc((void **)&w.d_pb_ctl, sizeof(int) * kPbCtlInts) != hipSuccess)
             return fail(LDPC_E_NOMEM, "PB-OSD control words could not be allocated");
-        if (!w.d_pb_cache && hipMalloc((void **)&w.d_pb_cache, sizeof(float) * (size_t)kPbTabSize * kPbHeavyGrid) != hipSuccess)
-            return fail(LDPC_E_NOMEM, "PB-OSD sum cache could not be allocated");
         (void)hipFree(w.d_pb_carry); w.d_pb_carry = nullptr;
         (void)hipFree(w.d_pb_prep); w.d_pb_prep = nullptr;
         if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * 3 * (size_t)frames) != hipSuccess ||
@@ -1253,6 +1307,7 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     if (rc) return rc;
     PbParams pp;
     pp.order = p->order; pp.nmax = (int)nmax; pp.cmin_off = spill_slots;
+    pp.t1 = 768; pp.t2 = 768; pp.t3 = 3072;   // 3/4 of the chunk capacities (measured flat between 512 and 1536 for stage A)
     pp.c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)p->snr_db / 10.0)));    // -4 * noise_variance, pb_testing.py:50-52
     const int mode = (p->reserved & 4) ? 2 : ((p->reserved & 2) ? 1 : 0);
     PbOut O{reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep, reinterpret_cast<int *>(p->d_aux)};
@@ -1268,23 +1323,22 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     const PbPrep *prep = mode == 0 ? prep_w : nullptr;    // (cross-check routes skip the stage that fills it)
     static const bool profile = getenv("LDPC_PB_PROFILE") != nullptr;   // diagnostic build of the two workgroup kernels
     if (!profile) {
-        hipLaunchKernelGGL((pb_block_kernel<256, 2048, false>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
+        hipLaunchKernelGGL((pb_block_kernel<256, 1024, false, 4>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
                            st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, (unsigned long long *)nullptr);
         hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, false>), dim3(g2b), dim3(1024), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_pb_tab, w->d_pb_cache, w->d_pb_ctl, listC, listB, carry, prep, O,
-                           (unsigned long long *)nullptr);
+                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, carry, prep, O, (unsigned long long *)nullptr);
     } else {
         static unsigned long long *d_prof = nullptr;
         if (!d_prof) LDPC_HIP(hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 48));
         LDPC_HIP(hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 48, s));
-        hipLaunchKernelGGL((pb_block_kernel<256, 2048, true>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
+        hipLaunchKernelGGL((pb_block_kernel<256, 1024, true, 4>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
                            st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, d_prof);
         hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, true>), dim3(g2b), dim3(1024), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_pb_tab, w->d_pb_cache, w->d_pb_ctl, listC, listB, carry, prep, O, d_prof + 24);
+                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, carry, prep, O, d_prof + 24);
         unsigned long long h[48];
         LDPC_HIP(hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, s));
         LDPC_HIP(hipStreamSynchronize(s));
-        static const char *names[24] = {"setup", "passA", "hist", "gather", "sort", "tie", "eval1", "eval2", "combine", "fill", "scatter",
+        static const char *names[24] = {"setup", "write(A)", "bound", "write(B)", "sort", "tie", "eval1", "eval2", "combine", "items", "scatter",
                                         "finish", "FRAMES", "CHUNKS", "FALLBACKS", "KEYS", "s.minmax", "s.count", "s.scan", "s.scatter",
                                         "s.fix", "MAXFRAMECYC", "MAXFRAMECHUNKS", "-"};
         for (int k = 0; k < 2; ++k) {

@@ -17,12 +17,11 @@ struct StreamWs {
     void *d_pb_carry = nullptr;       // PB-OSD: [pb_cap] search state of the frames on list C
     void *d_pb_prep = nullptr;        // PB-OSD: [pb_cap] per-frame probabilities / CDF table of the frames handed on (1 KiB each)
     int64_t pb_cap = 0;
-    float *d_pb_cache = nullptr;      // PB-OSD stage B: the 43 744 reliability sums of a frame, per workgroup
     void *d_pb_spill = nullptr;       // PB-OSD sequential kernel: frontier overflow [waves][stride]
     int64_t pb_spill_stride = 0;
 };
 constexpr int kPbCtlInts = 8;         // {-, list A length, ticket A, list B length, ticket B, list C length, ticket C, -}
-constexpr int kPbHeavyGrid = 512;     // grid of the stage-B PB kernel (each workgroup owns a 171 KiB sum cache)
+constexpr int kPbHeavyGrid = 512;     // grid of the stage-B PB kernel (frames are drawn by ticket)
 constexpr int kPbSeqBlocks = 64;      // grid of the sequential PB kernel (each of its 4 x 64 waves owns a spill area)
 
 struct OsdState {

@@ -49,3 +49,78 @@ def test_visit_order_comparator_on_ties():
     w2 = w.copy(); w2[63] = 0.0                   # {p} and {p, 63} tie: parent before child
     assert M.visit_less(w2, (10,), (10, 63)) and not M.visit_less(w2, (10, 63), (10,))
     assert M.visit_less(w2, (62, 63), (61,))     # both children of {62}, equal sums: the extended one first
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The direct enumeration of a sum range (csrc/ldpc_osd_pb.hip, PbItems): item layout, table-id formulas, the binary
+# search and the empty-item shortcut, restated in NumPy float32 and checked against a brute-force filter of the kernel's
+# TEP table.
+# ---------------------------------------------------------------------------------------------------------------------
+def _device_table():
+    tab = [(p, 0, 0, 1) for p in range(63, -1, -1)]
+    tab += [(p0, p1, 0, 2) for p0 in range(62, -1, -1) for p1 in range(p0 + 1, 64)]
+    tab += [(p0, p1, p2, 3) for p0 in range(61, -1, -1) for p1 in range(p0 + 1, 63) for p2 in range(p1 + 1, 64)]
+    return np.array(tab, dtype=np.int64)
+
+
+def _first_le(w, sb, base, T):
+    lo, hi = base + 1, 64
+    for _ in range(7):
+        mid = (lo + hi) >> 1
+        act, ok = lo < hi, np.float32(sb + w[min(mid, 63)]) <= T
+        if act and ok:
+            hi = mid
+        elif act:
+            lo = mid + 1
+    return lo
+
+
+def _enumerate(tab, w, lo, hi, order):
+    nitems = 2080 if order > 2 else (64 if order > 1 else 1)
+    out = []
+    for it in range(nitems):
+        if it == 0:
+            sb, base, idb = np.float32(0), -1, None
+        elif it < 64:
+            i = it - 1
+            m = 63 - i
+            sb, base, idb = w[i], i, 64 + m * (m - 1) // 2 - (i + 1)
+        else:
+            i, j = int(tab[it][0]), int(tab[it][1])
+            m, r = 63 - i, 64 - j
+            sb, base = np.float32(w[i] + w[j]), j
+            idb = 2080 + m * (m - 1) * (m - 2) // 6 + m * (m - 1) // 2 - r * (r - 1) // 2 - (j + 1)
+        e = 64 if (lo < 0 or base >= 63) else _first_le(w, sb, base, lo)
+        a = e
+        if base + 1 < e and np.float32(sb + w[63]) <= hi:
+            a = min(_first_le(w, sb, base, hi), e)
+        for mm in range(a, e):
+            out.append((63 - mm if base < 0 else idb + mm, np.float32(sb + w[mm])))
+    return out
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_sum_range_enumeration(order):
+    tab = _device_table()
+    nall = {1: 64, 2: 2080, 3: 43744}[order]
+    rng = np.random.default_rng(5 + order)
+    for case in range(6):
+        w = np.sort(np.abs(rng.normal(1.0, 0.6, 64)).astype(np.float32))[::-1].copy()
+        if case == 1:
+            w = (np.round(w * 8) / 8).astype(np.float32)      # many equal values
+        if case == 2:
+            w[40:] = 0.0
+        s = w[tab[:nall, 0]].copy()
+        s[tab[:nall, 3] > 1] = (s + w[tab[:nall, 1]])[tab[:nall, 3] > 1]
+        s[tab[:nall, 3] > 2] = (s + w[tab[:nall, 2]])[tab[:nall, 3] > 2]
+        bounds = [np.float32(-1.0), w[0], np.float32(w[0] * 1.4), np.float32(w[0] * 2.2), np.float32(np.inf)]
+        seen = np.zeros(nall, dtype=bool)
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            got = _enumerate(tab, w, lo, hi, order)
+            ids = np.array([g[0] for g in got], dtype=np.int64)
+            want = np.flatnonzero((s > lo) & (s <= hi))
+            assert np.array_equal(np.sort(ids), want), (order, case, lo, hi)
+            assert all(np.float32(v) == s[i] for i, v in got)        # the sums are the table's sums, bit for bit
+            assert not seen[ids].any()
+            seen[ids] = True
+        assert seen.all()
