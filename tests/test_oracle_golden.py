@@ -167,13 +167,13 @@ def test_pb_deterministic_math_is_accurate():
 def test_pb_osd_c_vs_numpy(np_code):
     """PB-OSD: the deterministic C restatement (det_expf, float64 CDF recurrence -- what the HIP kernels are bit-exact
     to) against the literal NumPy/SciPy one (pb_testing.py:100-149: np.exp, scipy.stats.binom.cdf).  Decisions may
-    differ only within float rounding of a threshold.  The full measurement (scripts/pb_oracle_gap.py, 11 594 NMS
+    differ only within float rounding of a threshold.  The full measurement (tests/tools/pb_oracle_gap.py, 11 594 NMS
     failures at 1.0 / 2.5 / 3.5 dB, orders 2 and 3, every search replayed to its end) is committed as
     profiles/r02/pb_oracle_gap.json: 2 frames differ (both at 1.0 dB, order 3: the promising rule fires one TEP
     earlier after ~10^4 TEPs), 0 codewords differ.  Here: a sample of each point, and the literal form of the script
     against np_oracle.pb_osd_frame itself."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("pb_oracle_gap", os.path.join(os.path.dirname(GOLDEN_ROOT), "scripts", "pb_oracle_gap.py"))
+    spec = importlib.util.spec_from_file_location("pb_oracle_gap", os.path.join(os.path.dirname(GOLDEN_ROOT), "tests", "tools", "pb_oracle_gap.py"))
     gap = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gap)
     total = differ = 0

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How far is the deterministic PB-OSD restatement (oracle/ldpc_oracle.c orc_pb_osd: det_expf, float64 CDF
+"""TEST INFRASTRUCTURE (uses oracle/; lives under tests/ for that reason).  How far is the deterministic PB-OSD restatement (oracle/ldpc_oracle.c orc_pb_osd: det_expf, float64 CDF
 recurrence -- the form the HIP kernel is bit-exact to) from the LITERAL restatement of
 PB_OSD/pb_testing.py:100-149 (NumPy exp, SciPy binom.cdf -- what the reference calls)?
 
@@ -10,7 +10,7 @@ in arrays (same operations, same float types; checked against np_oracle.pb_osd_f
 frames of every point).  Frames whose search runs past --cap TEPs are not compared (the literal Python loop is
 quadratic in the frontier) and are reported as skipped.
 
-    python scripts/pb_oracle_gap.py [--frames 2000] [--out profiles/r02/pb_oracle_gap.json]
+    python tests/tools/pb_oracle_gap.py [--frames 2000] [--out profiles/r02/pb_oracle_gap.json]
 """
 from __future__ import annotations
 
@@ -22,7 +22,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
