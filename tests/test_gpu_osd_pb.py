@@ -101,3 +101,15 @@ def test_pb_tie_heavy_inputs(dec, quant):
     for order in (2, 3):
         ref = _check(dec, y[idx], cw[idx], order, 2.5, None)
         _check(dec, y[idx], cw[idx], order, 2.5, "block", ref)
+
+
+@pytest.mark.parametrize("scale", [16.0, 1.0 / 64.0, 1000.0])
+def test_pb_other_input_scalings(dec, scale):
+    """The chunk bounds are sized relative to the frame's own reliabilities (pb_pick_bound): other scalings of the
+    channel values (LLR-scaled inputs) with the SNR parameter moved along take the same route through the kernels."""
+    y, cw = _failures(dec, 2.5, 1200, seed=91)
+    y, cw = (y[:200] * np.float32(scale)).astype(np.float32), cw[:200]
+    snr = 2.5 + 10.0 * np.log10(scale)
+    ref = _check(dec, y, cw, 3, snr, None)
+    assert ref["num_teps"].max() > 1000
+    _check(dec, y, cw, 3, snr, "block", ref)
