@@ -153,6 +153,9 @@ int ldpc_unpack_bits(ldpc_ctx *ctx, const uint64_t *d_words, int64_t B, void *d_
  * OSD (n = 128, k = 64 codes).  Frames are addressed as d_y[ d_index ? d_index[f] : f ].
  * If d_count is non-NULL the number of frames is min(*d_count, F) read ON THE DEVICE (so a
  * compaction can feed the OSD without a host round trip); F is then the capacity.
+ * The entries of d_index are frame numbers of d_y and are NOT range-checked (the entry points do not know
+ * how many frames d_y holds): a caller-made list must stay inside d_y; ldpc_compact / ldpc_pipeline_run
+ * write only valid, ascending frame numbers, from scratch that belongs to the call's stream.
  * ------------------------------------------------------------------------------------- */
 
 /* Pre-size OSD workspaces (640 B per frame: permutation + reduced parity rows) for up to max_frames
