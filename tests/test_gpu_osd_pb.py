@@ -76,7 +76,7 @@ def test_pb_full_scan_and_spill(dec):
 
 
 def test_pb_long_searches_order3(dec):
-    """1.0 dB, order 3: searches of thousands of TEPs -- chunks split by the histogram, the +inf threshold, full scans."""
+    """1.0 dB, order 3: searches of thousands of TEPs -- many chunks per frame (bounds sized by exact counts), the +inf bound, full scans."""
     y, cw = _failures(dec, 1.0, 120, seed=77)
     y, cw = y[:48], cw[:48]
     ref = _check(dec, y, cw, 3, 1.0, None)
