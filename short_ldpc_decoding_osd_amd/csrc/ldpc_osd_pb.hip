@@ -291,18 +291,8 @@ __device__ __forceinline__ void pb_write(SearchLds &L, const SearchFrame &S, con
 }
 
 // inclusive wave scans (lane order)
-__device__ __forceinline__ float wave_incl_min(float v, int lane)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const float t = __shfl_up(v, off, 64); if (lane >= off) v = __builtin_fminf(v, t); }
-    return v;
-}
-__device__ __forceinline__ int wave_incl_add(int v, int lane)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
-    return v;
-}
+__device__ __forceinline__ float wave_incl_min(float v, int) { return wave_incl_min_dpp(v); }
+__device__ __forceinline__ int wave_incl_add(int v, int) { return wave_incl_add_dpp(v); }
 
 // ---------------------------------------------------------------------------------------
 // stage 1: the weight-1 head of the pop sequence, one frame per wavefront, one TEP per lane

@@ -89,6 +89,19 @@ __device__ __forceinline__ int wave_incl_add_dpp(int x)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
     return v;
 }
+// inclusive prefix minimum over the lanes, same DPP ladder (a lane without a source keeps its own value)
+__device__ __forceinline__ float wave_incl_min_dpp(float x)
+{
+    int v = __float_as_int(x);
+    const auto step = [](int v, int got) { return __float_as_int(__builtin_fminf(__int_as_float(v), __int_as_float(got))); };
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));
+    return __int_as_float(v);
+}
 // lane that holds the smallest (value, index) pair; ties on value go to the lower index
 __device__ __forceinline__ int wave_argmin_lane(float s, int idx)
 {
