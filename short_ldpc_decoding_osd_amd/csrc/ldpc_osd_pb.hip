@@ -768,7 +768,7 @@ __device__ int pb_process_chunk(PbBlockLds<NT, CAP> &B, const uchar4 *__restrict
         const PbTep t{tq4[q].x, tq4[q].y, tq4[q].z, tq4[q].w};
         u64 E;
         pb_apply(L, t, d0, Dq[q], E);
-        cq[q] = valid ? tep_cost(L, __uint_as_float((unsigned)(kq[q] >> 32)), Dq[q]) : __builtin_inff();
+        cq[q] = valid ? tep_cost_wide(L, __uint_as_float((unsigned)(kq[q] >> 32)), Dq[q]) : __builtin_inff();
         dq[q] = valid ? pb_delta(t, P.order) : 0;
         tmin = __builtin_fminf(tmin, cq[q]);
         tdel += dq[q];

@@ -26,6 +26,18 @@ __device__ __forceinline__ float tep_cost(const SearchLds &L, float mrb, u64 D)
     return acc;
 }
 
+// The same sum with the eight LUT reads issued together (their LDS round trips overlap; the compiler, left to the form
+// above under register pressure, issues read - wait - add eight times over).  The empty asm pins the reads before the adds.
+__device__ __forceinline__ float tep_cost_wide(const SearchLds &L, float mrb, u64 D)
+{
+    float t0 = lut_term<0>(L, D), t1 = lut_term<1>(L, D), t2 = lut_term<2>(L, D), t3 = lut_term<3>(L, D);
+    float t4 = lut_term<4>(L, D), t5 = lut_term<5>(L, D), t6 = lut_term<6>(L, D), t7 = lut_term<7>(L, D);
+    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7));
+    float acc = mrb + t0;
+    acc = acc + t1; acc = acc + t2; acc = acc + t3; acc = acc + t4; acc = acc + t5; acc = acc + t6; acc = acc + t7;
+    return acc;
+}
+
 // The same sum with an exact early exit: every term is >= 0, so once the prefix (MRB weights + the two
 // most reliable parity bytes) exceeds an upper bound of the final minimum the candidate can neither win
 // nor tie, and its six remaining LUT reads are skipped (the scan is LDS-bound: random LUT reads, 63 % of
