@@ -628,12 +628,7 @@ __device__ __forceinline__ float pb_pick_bound(PbBlockLds<NT, CAP> &B, PbItems<N
 template <int NT, int CAP>
 __device__ __forceinline__ void pb_reduce3(PbBlockLds<NT, CAP> &B, int &cnt, float &mn, float &mx, int lane, int wave)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        cnt += __shfl_xor(cnt, off, 64);
-        mn = __builtin_fminf(mn, __shfl_xor(mn, off, 64));
-        mx = __builtin_fmaxf(mx, __shfl_xor(mx, off, 64));
-    }
+    cnt = wave_add_i32(cnt); mn = wave_min_f32(mn); mx = wave_max_f32(mx);     // (DPP: no ds_bpermute round trips)
     if (lane == 0) { B.red_i[0][wave] = cnt; B.red_f[0][wave] = mn; B.red_f[1][wave] = mx; }
     __syncthreads();
     cnt = 0; mn = __builtin_inff(); mx = -1.0f;
@@ -793,19 +788,30 @@ __device__ int pb_process_chunk(PbBlockLds<NT, CAP> &B, const uchar4 *__restrict
     float lbest = 0.0f;
     u64 lD = 0;
     uchar4 lt = make_uchar4(0, 0, 0, 0);
+    // rule 1 of all my entries first -- independent of each other once "the best before entry q" (a running minimum of the
+    // costs: up to the first stop every entry is evaluated) is known, so their exp / divide / CDF reads overlap -- then
+    // the sequential pass
+    bool npq[PER];
+    float w1q[PER];
+    {
+        float bef = before;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            npq[q] = pb_not_promising(__uint_as_float((unsigned)(kq[q] >> 32)), bef, Fr, P.c4, B.cdfA, B.cdfH, w1q[q]);
+            bef = __builtin_fminf(bef, cq[q]);       // (an invalid entry has cost +inf)
+        }
+    }
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         if (q < per && i0 + q < n && lstop == 0x7FFFFFFF) {
-            const float rs = __uint_as_float((unsigned)(kq[q] >> 32));
             ones += nlb == 1;
             nlb += dq[q];
-            float w1;
-            if (pb_not_promising(rs, before, Fr, P.c4, B.cdfA, B.cdfH, w1)) { lstop = i0 + q; lreason = 1; }
+            if (npq[q]) { lstop = i0 + q; lreason = 1; }
             else {
                 ++nev;
                 if (cq[q] < before) {
                     before = cq[q]; lnb = i0 + q; ++nnb; lbest = cq[q]; lD = Dq[q]; lt = tq4[q];
-                    if (pb_success(Dq[q], w1, B.tq, Fr)) { lstop = i0 + q; lreason = 2; }
+                    if (pb_success(Dq[q], w1q[q], B.tq, Fr)) { lstop = i0 + q; lreason = 2; }
                 }
             }
         }
@@ -817,12 +823,7 @@ __device__ int pb_process_chunk(PbBlockLds<NT, CAP> &B, const uchar4 *__restrict
     {   // my entries count if they lie before (or contain) the first stop; wave sums first, one atomic set per wavefront
         const bool mine = i0 < i1 && i0 <= gstop;
         int o = mine ? ones : 0, e = mine ? nev : 0, b = mine ? nnb : 0, l = mine ? lnb : -1;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            o += __shfl_xor(o, off, 64); e += __shfl_xor(e, off, 64); b += __shfl_xor(b, off, 64);
-            const int t = __shfl_xor(l, off, 64);
-            l = t > l ? t : l;
-        }
+        o = wave_add_i32(o); e = wave_add_i32(e); b = wave_add_i32(b); l = wave_max_i32(l);
         if (lane == 0) { atomicAdd(&B.ones, o); atomicAdd(&B.nev, e); atomicAdd(&B.nnb, b); atomicMax(&B.lnb, l); }
         if (mine && lstop == gstop) B.reason = lreason;
     }

@@ -76,6 +76,21 @@ __device__ __forceinline__ int wave_max_i32(int x)
     { const int ID = (int)0x80000000; LDPC_WAVE_REDUCE(v, op_max_i) }
     return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ int op_max_f(int a, int b) { return __float_as_int(__builtin_fmaxf(__int_as_float(a), __int_as_float(b))); }
+__device__ __forceinline__ int op_add_i(int a, int b) { return a + b; }
+// maximum of floats >= -1 over the wave / sum of ints over the wave, result in every lane
+__device__ __forceinline__ float wave_max_f32(float x)
+{
+    int v = __float_as_int(x);
+    { const int ID = (int)0xBF800000; LDPC_WAVE_REDUCE(v, op_max_f) }
+    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
+__device__ __forceinline__ int wave_add_i32(int x)
+{
+    int v = x;
+    { const int ID = 0; LDPC_WAVE_REDUCE(v, op_add_i) }
+    return __builtin_amdgcn_readlane(v, 63);
+}
 // inclusive prefix sum over the lanes (lane l gets x_0 + ... + x_l): row_shr DPP steps inside a row of 16, then the
 // row totals by row_bcast:15 / row_bcast:31
 __device__ __forceinline__ int wave_incl_add_dpp(int x)
