@@ -339,16 +339,35 @@ __global__ __launch_bounds__(64) void osd_search2_kernel(const float *__restrict
 //    frame f is scanned, so the ~2 us of dependent global latency of the prologue is hidden;
 //  * everything else (two-stage scan with the exact prefix bound, survivor ring, rank-ordered ties) as above.
 // ---------------------------------------------------------------------------------------
+// LDS of the rotation scan: the byte LUT and the survivor ring, exactly 10 KiB -> 16 workgroups = 4 wavefronts per SIMD
+// (the scan is occupancy-sensitive: 1.75x the time at half the residency).  The parity weights are only needed while the
+// LUT is built and the codeword words only after the last survivor batch, so both borrow the ring's memory.
+struct __attribute__((aligned(16))) Search2rLds {
+    float lut[8][256];   // lut[b][v] = sum of |y'[64+8b+t]| over the set bits t of v, ascending t
+    uint4 q[128];        // survivors: D.lo, D.hi, prefix metric bits, r * 64 + lane
+    __device__ __forceinline__ float *wpar() { return reinterpret_cast<float *>(q); }           // [64], before the scan
+    __device__ __forceinline__ u64 *cw() { return reinterpret_cast<u64 *>(q) + 32; }            // [2], after the scan
+};
+static_assert(sizeof(Search2rLds) == 10240, "LDS budget of the rotation scan");
+
+__device__ __forceinline__ float cost2r(const Search2rLds &L, float mrb, u64 D)
+{
+    float acc = mrb;
+    acc = acc + lut_byte<0>(L.lut, D); acc = acc + lut_byte<1>(L.lut, D); acc = acc + lut_byte<2>(L.lut, D); acc = acc + lut_byte<3>(L.lut, D);
+    acc = acc + lut_byte<4>(L.lut, D); acc = acc + lut_byte<5>(L.lut, D); acc = acc + lut_byte<6>(L.lut, D); acc = acc + lut_byte<7>(L.lut, D);
+    return acc;
+}
+
 __device__ __forceinline__ int wave_rot1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x134, 0xF, 0xF, true); }
 
-__device__ __forceinline__ void search2r_finish_batch(const SearchLds &L, uint4 e, bool valid, int dir, const int *__restrict__ base2,
+__device__ __forceinline__ void search2r_finish_batch(const Search2rLds &L, uint4 e, bool valid, int dir, const int *__restrict__ base2,
                                                       float &best, int &bi, int &bj, u64 &bestD)
 {
     if (!valid) return;
     const u64 D = ((u64)e.y << 32) | e.x;
     float acc = __uint_as_float(e.z);
-    acc = acc + lut_term<2>(L, D); acc = acc + lut_term<3>(L, D); acc = acc + lut_term<4>(L, D);
-    acc = acc + lut_term<5>(L, D); acc = acc + lut_term<6>(L, D); acc = acc + lut_term<7>(L, D);
+    acc = acc + lut_byte<2>(L.lut, D); acc = acc + lut_byte<3>(L.lut, D); acc = acc + lut_byte<4>(L.lut, D);
+    acc = acc + lut_byte<5>(L.lut, D); acc = acc + lut_byte<6>(L.lut, D); acc = acc + lut_byte<7>(L.lut, D);
     if (!(acc <= best)) return;
     const int r = (int)(e.w >> 6), l = (int)(e.w & 63), m = (l - dir * r) & 63;
     const int ci = l < m ? l : m, cj = l < m ? m : l;
@@ -356,18 +375,18 @@ __device__ __forceinline__ void search2r_finish_batch(const SearchLds &L, uint4 
     if (acc < best || tep2_rank(ci, cj, base2) < tep2_rank(bi, bj, base2)) { best = acc; bi = ci; bj = cj; bestD = D; }
 }
 
-__device__ __forceinline__ void search2r_device(Search2Lds &LL, const SearchFrame &S, u64 Pl, float wl, int dir,
+__device__ __forceinline__ void search2r_device(Search2rLds &LL, const SearchFrame &S, u64 Pl, float wl, int dir,
                                                 const int *__restrict__ base2, int lane, float &best_out, int &rank_out,
                                                 u64 &D_out, u64 &E_out)
 {
-    SearchLds &L = LL.s;
+    Search2rLds &L = LL;
     // order 0 (rank 0, identical in every lane), then order 1: lane l owns TEP {l}
-    float best = tep_cost(L, 0.0f, S.d0);
+    float best = cost2r(L, 0.0f, S.d0);
     int bi = -1, bj = -1;
     u64 bestD = S.d0;
     const u64 dP = S.d0 ^ Pl;
     {
-        const float c = tep_cost(L, wl, dP);
+        const float c = cost2r(L, wl, dP);
         if (c < best) { best = c; bj = lane; bestD = dP; }      // a tie keeps the lower rank (order 0)
     }
     float bound = wave_min_f32(best);
@@ -377,11 +396,11 @@ __device__ __forceinline__ void search2r_device(Search2Lds &LL, const SearchFram
     // (bank conflicts included) overlaps the survivor bookkeeping -- at 3.5 wavefronts per SIMD nothing else hides it
     plo = wave_rot1(plo); phi = wave_rot1(phi); wr = wave_rot1(wr);
     u64 D = dP ^ (((u64)(unsigned)phi << 32) | (unsigned)plo);
-    float m = wl + __int_as_float(wr), t0 = lut_term<0>(L, D), t1 = lut_term<1>(L, D);
+    float m = wl + __int_as_float(wr), t0 = lut_byte<0>(L.lut, D), t1 = lut_byte<1>(L.lut, D);
     for (int r = 1; r <= 32; ++r) {
         plo = wave_rot1(plo); phi = wave_rot1(phi); wr = wave_rot1(wr);          // (round 33 is computed and never used)
         const u64 Dn = dP ^ (((u64)(unsigned)phi << 32) | (unsigned)plo);
-        const float mn = wl + __int_as_float(wr), u0 = lut_term<0>(L, Dn), u1 = lut_term<1>(L, Dn);
+        const float mn = wl + __int_as_float(wr), u0 = lut_byte<0>(L.lut, Dn), u1 = lut_byte<1>(L.lut, Dn);
         float acc = m + t0;                                                       // |y'_i| + |y'_j| (commutative), then byte 0
         acc = acc + t1;
         const bool keep = (r < 32 || lane < 32) && !(acc > bound);
@@ -428,8 +447,7 @@ __global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restric
                                                           int *__restrict__ best_out, int *__restrict__ ntep_out,
                                                           const u64 *__restrict__ label, u64 *__restrict__ counts)
 {
-    __shared__ Search2Lds LL;
-    SearchLds &L = LL.s;
+    __shared__ Search2rLds LL;
     const int lane = threadIdx.x;
     long long nframes = F;
     if (count) { const long long c = *count; nframes = c < F ? c : F; }
@@ -469,22 +487,24 @@ __global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restric
         SearchFrame S;
         S.o1 = o1a; S.o2 = o2a;
         const float w1 = __builtin_fabsf(y1a), w2 = __builtin_fabsf(y2a);
-        L.w[lane + 64] = w2;
-        if (lane < 2) L.cw[lane] = 0;
+        LL.wpar()[lane] = w2;
         S.hm = __ballot(!(y1a > 0.0f));
         S.hp = __ballot(!(y2a > 0.0f));
         wave_fence();
-        build_byte_luts<8>(L.lut, &L.w[64], lane);
+        build_byte_luts<8>(LL.lut, LL.wpar(), lane);
         S.d0 = wave_xor64(((S.hm >> lane) & 1) ? Pa : 0ull) ^ S.hp;
         wave_fence();
         float best; int bestt; u64 bestD, bestE;
         search2r_device(LL, S, Pa, w1, dir, base2, lane, best, bestt, bestD, bestE);
         {   // search_finish, with the codeword words still in hand for the success test (convention_osd.py:65-66)
             const u64 mrb_bits = S.hm ^ bestE, par_bits = bestD ^ S.hp;
-            if ((mrb_bits >> lane) & 1) atomicOr(&L.cw[S.o1 >> 6], 1ull << (S.o1 & 63));
-            if ((par_bits >> lane) & 1) atomicOr(&L.cw[S.o2 >> 6], 1ull << (S.o2 & 63));
+            u64 *const cw = LL.cw();
+            if (lane < 2) cw[lane] = 0;
             wave_fence();
-            const u64 word = lane < 2 ? L.cw[lane] : 0ull;
+            if ((mrb_bits >> lane) & 1) atomicOr(&cw[S.o1 >> 6], 1ull << (S.o1 & 63));
+            if ((par_bits >> lane) & 1) atomicOr(&cw[S.o2 >> 6], 1ull << (S.o2 & 63));
+            wave_fence();
+            const u64 word = lane < 2 ? cw[lane] : 0ull;
             if (lane < 2) cw_out[f0 * 2 + lane] = word;
             if (counts && __ballot(lane < 2 && word != laba) && lane == 0) atomicAdd(&counts[1], 1ull);
             wave_fence();
@@ -864,10 +884,10 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
                            d_perm, d_parity, st->d_tep_fs, fp, reinterpret_cast<u64 *>(d_cw), d_metric, d_best,
                            d_ntep);
     } else if (p->order == 2 && !(p->reserved & 1) && ctx->dpp_wave_rol_dir != 0 && !(p->reserved & 8)) {
-        // 3.5 wavefronts per SIMD are resident (11 KiB of LDS each); the grid is 6x that, ~1.5 frames per workgroup at the
+        // 4 wavefronts per SIMD are resident (10 KiB of LDS each); the grid is 6x that, ~1.5 frames per workgroup at the
         // headline size: the dispatcher then evens out the different scan times, and the prefetch still covers the second
         // frame (measured, 33 487 frames: 1x 119 us, 2x 117, 3x 108, 4x 107, 6x 100, 9x 102 per call incl. events)
-        const long long grid = (long long)ctx->cu_count * 14 * 6;
+        const long long grid = (long long)ctx->cu_count * 16 * 6;
         hipLaunchKernelGGL(osd_search2r_kernel, dim3((unsigned)(F < grid ? F : grid)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
                            d_perm, d_parity, ctx->dpp_wave_rol_dir, st->d_base2, reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep,
                            reinterpret_cast<const u64 *>(d_label), d_label ? reinterpret_cast<u64 *>(d_counts) : nullptr);
