@@ -136,8 +136,15 @@ __device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, 
         spl = spl * (1.0f - q[p]);
     }
     const float p1 = a1 / 64.0f, lrb_mean = aw / 64.0f, pt = at / 64.0f;
-    // binomial CDF tables by the pmf recurrence (float64): full table for p1, up to `order` for pt
+    // binomial CDF tables by the pmf recurrence (float64): full table for p1, up to `order` for pt.  Lane i holds the
+    // i-th coefficient; the dependent chain takes it by v_readlane (a scalar load per step sat on the critical path).
     double niu;
+    const double coef_l = kPbCoef.v[lane];
+    const auto coef = [coef_l](int i) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(coef_l);
+        const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, i), hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), i);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
     {
         double qq = 1.0 - (double)p1, t = qq;
         for (int s = 0; s < 6; ++s) t = t * t;
@@ -146,7 +153,7 @@ __device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, 
         if (lane == 0) cdfA[0] = acc;
 #pragma unroll 2
         for (int i = 0; i < 64; ++i) {
-            t = t * kPbCoef.v[i] * ratio;
+            t = t * coef(i) * ratio;
             acc = acc + t;
             if (lane == 0) cdfA[i + 1] = acc;
         }
@@ -154,7 +161,7 @@ __device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, 
         for (int s = 0; s < 6; ++s) t = t * t;
         const double ratio2 = (double)pt / qq;
         acc = t;
-        for (int i = 0; i < order; ++i) { t = t * kPbCoef.v[i] * ratio2; acc = acc + t; }
+        for (int i = 0; i < order; ++i) { t = t * coef(i) * ratio2; acc = acc + t; }
         niu = acc;
     }
     PbFrame F;
@@ -305,7 +312,8 @@ struct PbSinglesLds {
     float2 tq[64];
 };
 
-__global__ __launch_bounds__(256) void pb_singles_kernel(const float *__restrict__ y, const int *__restrict__ index,
+// (one wavefront per workgroup: 11.2 KiB of LDS each, 14 resident per CU -- four per workgroup left 12)
+__global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                          const int *__restrict__ count, long long F,
                                                          const unsigned char *__restrict__ perm_in,
                                                          const u64 *__restrict__ parity_in, PbParams P, int mode,
@@ -313,22 +321,21 @@ __global__ __launch_bounds__(256) void pb_singles_kernel(const float *__restrict
                                                          int *__restrict__ ctl, int *__restrict__ listA, int *__restrict__ listB,
                                                          PbPrep *__restrict__ prep, PbOut O)
 {
-    __shared__ PbSinglesLds lds[4];
-    const int lane = threadIdx.x & 63;
-    PbSinglesLds &W = lds[threadIdx.x >> 6];
+    __shared__ PbSinglesLds W;
+    const int lane = threadIdx.x;
     SearchLds &L = W.s;
     long long nframes = F;
     if (count) { const long long c = *count; nframes = c < F ? c : F; }
-    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long wave = blockIdx.x;
     if (mode != 0) {   // hand every frame on, in frame order
-        for (long long f = wave * 64 + lane; f < nframes; f += (long long)gridDim.x * 256) (mode == 1 ? listA : listB)[f] = (int)f;
+        for (long long f = wave * 64 + lane; f < nframes; f += (long long)gridDim.x * 64) (mode == 1 ? listA : listB)[f] = (int)f;
         if (wave == 0 && lane == 0) ctl[mode == 1 ? 1 : 3] = (int)nframes;
         return;
     }
     W.cdfH[lane] = cdf_half[lane];
     if (lane == 0) W.cdfH[64] = cdf_half[64];
     wave_fence();
-    for (long long f = wave; f < nframes; f += (long long)gridDim.x * 4) {
+    for (long long f = wave; f < nframes; f += gridDim.x) {
         const long long src = index ? index[f] : f;
         const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
         const PbFrame Fr = pb_frame_setup(L, W.q, W.cdfA, P.c4, P.order, P.nmax, lane);
@@ -1306,8 +1313,8 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     PbPrep *prep_w = reinterpret_cast<PbPrep *>(w->d_pb_prep);
     LDPC_HIP(hipMemsetAsync(w->d_pb_ctl, 0, sizeof(int) * kPbCtlInts, s));
     const int64_t want = (F + 3) / 4;
-    const unsigned g1 = (unsigned)(want < 1 ? 1 : (want < 8192 ? want : 8192));
-    hipLaunchKernelGGL(pb_singles_kernel, dim3(g1), dim3(256), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
+    const unsigned g1 = (unsigned)(F < 1 ? 1 : (F < 32768 ? F : 32768));
+    hipLaunchKernelGGL(pb_singles_kernel, dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
                        st->d_cdf_half, w->d_pb_ctl, listA, listB, prep_w, O);
     const unsigned g2 = (unsigned)(F < 1024 ? F : 1024), g2b = (unsigned)(F < kPbHeavyGrid ? F : kPbHeavyGrid);
     PbCarry *carry = reinterpret_cast<PbCarry *>(w->d_pb_carry);
