@@ -631,45 +631,26 @@ __device__ __forceinline__ float pb_pick_bound(PbBlockLds<NT, CAP> &B, PbItems<N
     return lo;
 }
 
-// block reductions of (count, min, max); every thread gets the results
-template <int NT, int CAP>
-__device__ __forceinline__ void pb_reduce3(PbBlockLds<NT, CAP> &B, int &cnt, float &mn, float &mx, int lane, int wave)
-{
-    cnt = wave_add_i32(cnt); mn = wave_min_f32(mn); mx = wave_max_f32(mx);     // (DPP: no ds_bpermute round trips)
-    if (lane == 0) { B.red_i[0][wave] = cnt; B.red_f[0][wave] = mn; B.red_f[1][wave] = mx; }
-    __syncthreads();
-    cnt = 0; mn = __builtin_inff(); mx = -1.0f;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) { cnt += B.red_i[0][w]; mn = __builtin_fminf(mn, B.red_f[0][w]); mx = __builtin_fmaxf(mx, B.red_f[1][w]); }
-    __syncthreads();
-}
-
 // The n gathered keys of one chunk (all TEPs of a sum range): sort into visit order, evaluate in parallel, apply
 // the sequential rules.  Returns 0 = no rule fired (B.j / B.nlive advanced), 1 = stopped (stop / ntep set),
 // 2 = a run of more than kPbMaxTie equal sums (frame goes to the list replay).
 template <int NT, int CAP, bool PROF>
 __device__ int pb_process_chunk(PbBlockLds<NT, CAP> &B, const uchar4 *__restrict__ tab, const PbParams &P, const PbFrame &Fr,
-                                u64 d0, int n, int tid, int &stop, int &ntep)
+                                u64 d0, int n, float mn, float mx, int tid, int &stop, int &ntep)
 {
     constexpr int W = NT / 64;
     SearchLds &L = B.s;
     const int lane = tid & 63, wave = tid >> 6;
     u64 *const K = B.gath;                              // the chunk in visit order ends up where it was gathered
-    // ---- bucket sort.  CAP buckets over [min, max] of the chunk's sums hold ~1 key each (<= ~14 near the dense upper
+    // ---- bucket sort.  CAP buckets over the chunk's sum range (mn, mx] -- its bounds, known to the caller -- hold ~1 key each (<= ~14 near the dense upper
     // end): counts -> offsets (scan) -> scatter into B.keys (grouped by bucket) -> every key counts the keys of its own
     // bucket that sort before it and lands at bucket start + rank in B.gath.  No dependent chains: a bitonic sort of the
     // same 1024 keys took 55 barrier-separated LDS steps (39 % of the stage-A kernel), an insertion sort inside the
     // buckets left one thread with ~50 dependent LDS round trips; this is ~8 barriers and independent reads.
     {
-        int dummy = 0;
-        float mn = __builtin_inff(), mx = -1.0f;
-        for (int i = tid; i < n; i += NT) {
-            const float sv = __uint_as_float((unsigned)(B.gath[i] >> 32));
-            mn = __builtin_fminf(mn, sv); mx = __builtin_fmaxf(mx, sv);
-        }
         for (int b = tid; b < CAP; b += NT) B.bucket[b] = 0;
         if (tid == 0) B.fallback = 0;
-        pb_reduce3(B, dummy, mn, mx, lane, wave);
+        __syncthreads();
         PB_STAMP(16);
         const float scale = mx > mn ? (float)CAP / (mx - mn) : 0.0f;
         const bool flat = !(scale < 3.0e38f);           // denormally close sums: one bucket
@@ -943,6 +924,7 @@ __global__ __launch_bounds__(NT, MINW) void pb_block_kernel(const float *__restr
         // Two chunks of increasing sums here (aimed at ~512, then ~1536 TEPs: 88 % / 96 % of the frames that reach this
         // kernel stop inside them); a frame that is still searching then goes to stage B with its state.
         pb_items_frame(I, L.w, -1.0f);
+        const float smax = P.order > 2 ? (L.w[0] + L.w[1]) + L.w[2] : (P.order > 1 ? L.w[0] + L.w[1] : L.w[0]);
         float lo = -1.0f;
         int done = 0;
         for (int chunk = 0; chunk < 2 && state == 0 && done < nall; ++chunk) {
@@ -953,7 +935,7 @@ __global__ __launch_bounds__(NT, MINW) void pb_block_kernel(const float *__restr
             pb_items_write(B, I, L.w, run);
             __syncthreads();
             PB_STAMP(kProfPassA);
-            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, tid, stop, ntep);
+            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, lo < 0.0f ? L.w[63] : lo, T < __builtin_inff() ? T : smax, tid, stop, ntep);
             lo = T;
             done += n;
         }
@@ -1034,6 +1016,7 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
         float lo = B.lo;
         int done = B.j;
         pb_items_frame(I, L.w, lo);
+        const float smax = P.order > 2 ? (L.w[0] + L.w[1]) + L.w[2] : L.w[0] + L.w[1];
         while (state == 0 && done < nall) {
             int n, run;
             const float T = pb_pick_bound(B, I, L.w, P.order, lo, done, nall, P.t3, lane, wave, n, run);
@@ -1042,7 +1025,7 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
             pb_items_write(B, I, L.w, run);
             __syncthreads();
             PB_STAMP(kProfGather);
-            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, tid, stop, ntep);
+            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, lo < 0.0f ? L.w[63] : lo, T < __builtin_inff() ? T : smax, tid, stop, ntep);
             lo = T;
             done += n;
         }
