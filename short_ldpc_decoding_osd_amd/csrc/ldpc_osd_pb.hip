@@ -983,7 +983,10 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
                                                       unsigned long long *__restrict__ prof_out)
 {
     constexpr int W = NT / 64;
-    __shared__ PbBlockLds<NT, CAP> B;
+    // (dynamic LDS: a hipGraph kernel node with more than 64 KiB of STATIC LDS aborts at replay on ROCm 7.2; the size is
+    //  registered once in pb_ctx_init)
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_heavy_lds[];
+    PbBlockLds<NT, CAP> &B = *reinterpret_cast<PbBlockLds<NT, CAP> *>(pb_heavy_lds);
     SearchLds &L = B.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nlist = ctl[5];
@@ -1224,9 +1227,20 @@ __global__ __launch_bounds__(256) void pb_seq_kernel(const float *__restrict__ y
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
+// the control words of a call start at zero (a one-wavefront kernel, not hipMemsetAsync: captured into a hipGraph the
+// memset node did not clear the words on the second and later replays -- ROCm 7.2 -- and the tickets ran on)
+__global__ __launch_bounds__(64) void pb_ctl_clear_kernel(int *__restrict__ ctl)
+{
+    if (threadIdx.x < kPbCtlInts) ctl[threadIdx.x] = 0;
+}
+
 int pb_ctx_init(ldpc_ctx *ctx)
 {
     OsdState *st = state(ctx);
+    LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_heavy_kernel<1024, 4096, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(PbBlockLds<1024, 4096>)));
+    LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_heavy_kernel<1024, 4096, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(PbBlockLds<1024, 4096>)));
     std::vector<uchar4> tab;
     tab.reserve(kPbTabSize);
     for (int p = 63; p >= 0; --p) tab.push_back(make_uchar4((unsigned char)p, 0, 0, 1));
@@ -1294,7 +1308,7 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     PbOut O{reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep, reinterpret_cast<int *>(p->d_aux)};
     int *listA = w->d_pb_list, *listB = w->d_pb_list + w->pb_cap, *listC = w->d_pb_list + 2 * w->pb_cap;
     PbPrep *prep_w = reinterpret_cast<PbPrep *>(w->d_pb_prep);
-    LDPC_HIP(hipMemsetAsync(w->d_pb_ctl, 0, sizeof(int) * kPbCtlInts, s));
+    hipLaunchKernelGGL(pb_ctl_clear_kernel, dim3(1), dim3(64), 0, s, w->d_pb_ctl);
     const int64_t want = (F + 3) / 4;
     const unsigned g1 = (unsigned)(F < 1 ? 1 : (F < 32768 ? F : 32768));
     hipLaunchKernelGGL(pb_singles_kernel, dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
@@ -1306,7 +1320,7 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     if (!profile) {
         hipLaunchKernelGGL((pb_block_kernel<256, 1024, false, 4>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
                            st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, (unsigned long long *)nullptr);
-        hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, false>), dim3(g2b), dim3(1024), 0, s, d_y, d_index, d_perm, d_parity, pp,
+        hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, false>), dim3(g2b), dim3(1024), sizeof(PbBlockLds<1024, 4096>), s, d_y, d_index, d_perm, d_parity, pp,
                            st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, carry, prep, O, (unsigned long long *)nullptr);
     } else {
         static unsigned long long *d_prof = nullptr;
@@ -1314,7 +1328,7 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
         LDPC_HIP(hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 48, s));
         hipLaunchKernelGGL((pb_block_kernel<256, 1024, true, 4>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
                            st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, d_prof);
-        hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, true>), dim3(g2b), dim3(1024), 0, s, d_y, d_index, d_perm, d_parity, pp,
+        hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, true>), dim3(g2b), dim3(1024), sizeof(PbBlockLds<1024, 4096>), s, d_y, d_index, d_perm, d_parity, pp,
                            st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, carry, prep, O, d_prof + 24);
         unsigned long long h[48];
         LDPC_HIP(hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, s));

@@ -1,0 +1,66 @@
+"""-m gpu: a decode step captured into a HIP graph (include/ldpc_osd.h: decode calls neither allocate nor
+synchronise once the stream's workspace exists) and replayed must produce what the eager call produces."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle
+from tests.gpu_util import pack_np, to_dev
+
+pytestmark = pytest.mark.gpu
+ALPHA0 = 0.669435
+
+
+@pytest.fixture(scope="module")
+def dec():
+    from short_ldpc_decoding_osd_amd import Code
+    from short_ldpc_decoding_osd_amd.runtime import Decoder
+    return Decoder(Code())
+
+
+def _snapshot(pipe):
+    n = int(pipe.count.cpu()[0])
+    return dict(count=n, index=pipe.index[:n].cpu().numpy().copy(), cw=pipe.cw[:n].cpu().numpy().copy(),
+                metric=pipe.metric[:n].cpu().numpy().copy(), hard=pipe.hard.cpu().numpy().copy(),
+                counters=pipe.counters().cpu().numpy().copy())
+
+
+@pytest.mark.parametrize("algo,order,B", [("conv", 2, 20000), ("pb", 3, 5000)])
+def test_pipeline_step_in_a_graph(dec, algo, order, B):
+    from short_ldpc_decoding_osd_amd import _lib
+    from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline
+    algo_id = {"conv": _lib.OSD_CONVENTIONAL, "pb": _lib.OSD_PB}[algo]
+    rng = np.random.default_rng(321)
+    y, cw = np_oracle.make_frames(dec.code.G, 2.5, B, rng)
+    pipe = BatchPipeline(dec, B, 10, ALPHA0, osd_order=order, osd_algo=algo_id, snr_db=2.5)
+    yd = to_dev(y, dec)
+    pipe.bind(yd, to_dev(pack_np(cw).view(np.int64), dec))
+    pipe.reset_counters()
+    pipe.run()
+    torch.cuda.synchronize()
+    want = _snapshot(pipe)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):          # one eager call on the capture stream sizes that stream's workspace
+        pipe.run()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        pipe.run()
+    # other inputs in the same buffers, then back: the replay must follow the buffers' contents
+    y2, cw2 = np_oracle.make_frames(dec.code.G, 2.5, B, np.random.default_rng(654))
+    yd.copy_(to_dev(y2, dec))
+    pipe.reset_counters()
+    graph.replay()
+    torch.cuda.synchronize()
+    other = _snapshot(pipe)
+    assert other["count"] != want["count"] or not np.array_equal(other["hard"], want["hard"])
+    yd.copy_(to_dev(y, dec))
+    pipe.reset_counters()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    got = _snapshot(pipe)
+    assert got["count"] == want["count"]
+    for k in ("index", "cw", "metric", "hard"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["counters"], 3 * want["counters"])
