@@ -25,14 +25,16 @@ def _snapshot(pipe):
                 counters=pipe.counters().cpu().numpy().copy())
 
 
-@pytest.mark.parametrize("algo,order,B", [("conv", 2, 20000), ("pb", 3, 5000)])
-def test_pipeline_step_in_a_graph(dec, algo, order, B):
+@pytest.mark.parametrize("algo,order,B,keep_front", [("conv", 2, 20000, True), ("pb", 3, 5000, True), ("fs", 2, 8000, True),
+                                                     ("conv", 2, 8000, False), ("pb", 2, 4000, False)])
+def test_pipeline_step_in_a_graph(dec, algo, order, B, keep_front):
     from short_ldpc_decoding_osd_amd import _lib
     from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline
-    algo_id = {"conv": _lib.OSD_CONVENTIONAL, "pb": _lib.OSD_PB}[algo]
+    algo_id = {"conv": _lib.OSD_CONVENTIONAL, "pb": _lib.OSD_PB, "fs": _lib.OSD_FS}[algo]
     rng = np.random.default_rng(321)
     y, cw = np_oracle.make_frames(dec.code.G, 2.5, B, rng)
-    pipe = BatchPipeline(dec, B, 10, ALPHA0, osd_order=order, osd_algo=algo_id, snr_db=2.5)
+    # keep_front=False: the OSD goes through ldpc_osd_decode and the capture stream's own workspace
+    pipe = BatchPipeline(dec, B, 10, ALPHA0, osd_order=order, osd_algo=algo_id, snr_db=2.5, keep_front=keep_front)
     yd = to_dev(y, dec)
     pipe.bind(yd, to_dev(pack_np(cw).view(np.int64), dec))
     pipe.reset_counters()
