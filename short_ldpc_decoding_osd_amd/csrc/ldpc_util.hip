@@ -281,12 +281,21 @@ int ldpc_eval_counts(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_la
     return LDPC_OK;
 }
 
+}  // extern "C"
+
+namespace ldpc {
+// (a kernel, not hipMemsetAsync: a memset node captured into a hipGraph did not run on later replays, ROCm 7.2)
+__global__ void zero_word_kernel(int32_t *p) { *p = 0; }
+}  // namespace ldpc
+
+extern "C" {
+
 int ldpc_compact(ldpc_ctx *ctx, const uint8_t *d_flag, int64_t B, int32_t *d_index, int32_t *d_count, void *stream)
 {
     if (!ctx || !d_count || B < 0 || B > 0x7FFFFFFFLL || (B > 0 && (!d_flag || !d_index)))
         return fail(LDPC_E_ARG, "ldpc_compact: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (B == 0) { LDPC_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return LDPC_OK; }
+    if (B == 0) { hipLaunchKernelGGL(ldpc::zero_word_kernel, dim3(1), dim3(1), 0, st, d_count); LDPC_HIP(hipGetLastError()); return LDPC_OK; }
     launch_compact<false>(d_flag, B, d_index, d_count, nullptr, nullptr, 0, nullptr, st);
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;
