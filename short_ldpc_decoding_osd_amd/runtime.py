@@ -134,6 +134,10 @@ class Decoder:
         """Pre-size the OSD workspace (needed before capturing decode calls into a graph)."""
         _lib.check(self.L.ldpc_osd_reserve(self._ctx, int(max_frames)), "ldpc_osd_reserve")
 
+    def osd_reserve_stream(self, max_frames):
+        """Pre-size the OSD workspace of the CURRENT stream (instead of one eager call on it before a capture)."""
+        _lib.check(self.L.ldpc_osd_reserve_stream(self._ctx, int(max_frames), self._stream()), "ldpc_osd_reserve_stream")
+
     def osd_ge(self, rows):
         """Device GF(2) elimination of [F,64,2] packed matrices -> (reduced, swaps[F,64,2] u8, nswaps[F])."""
         self._chk(rows, torch.int64, (64, 2), "rows")

@@ -66,3 +66,31 @@ def test_pipeline_step_in_a_graph(dec, algo, order, B, keep_front):
     for k in ("index", "cw", "metric", "hard"):
         assert np.array_equal(got[k], want[k]), k
     assert np.array_equal(got["counters"], 3 * want["counters"])
+
+
+def test_capture_after_reserve_stream(dec):
+    """ldpc_osd_reserve_stream sizes the capture stream's workspace: the first OSD call on that stream may be the captured one."""
+    from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline
+    B = 6000
+    y, cw = np_oracle.make_frames(dec.code.G, 2.5, B, np.random.default_rng(77))
+    pipe = BatchPipeline(dec, B, 10, ALPHA0, osd_order=2, keep_front=False)
+    pipe.bind(to_dev(y, dec), to_dev(pack_np(cw).view(np.int64), dec))
+    pipe.reset_counters()
+    pipe.run()
+    torch.cuda.synchronize()
+    want = _snapshot(pipe)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        dec.osd_reserve_stream(B)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        pipe.run()
+    pipe.reset_counters()
+    graph.replay()
+    graph.replay()
+    torch.cuda.synchronize()
+    got = _snapshot(pipe)
+    for k in ("index", "cw", "metric", "hard"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["counters"], 2 * want["counters"])
