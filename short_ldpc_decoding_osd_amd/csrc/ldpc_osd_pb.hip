@@ -313,14 +313,18 @@ struct PbSinglesLds {
 };
 
 // (one wavefront per workgroup: 11.2 KiB of LDS each, 14 resident per CU -- four per workgroup left 12)
+template <bool PROF>
 __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                          const int *__restrict__ count, long long F,
                                                          const unsigned char *__restrict__ perm_in,
                                                          const u64 *__restrict__ parity_in, PbParams P, int mode,
                                                          const double *__restrict__ cdf_half,
-                                                         int *__restrict__ ctl, int *__restrict__ listA, int *__restrict__ listB,
-                                                         PbPrep *__restrict__ prep, PbOut O)
+                                                         int *__restrict__ ctl, int *__restrict__ listA, int *__restrict__ listB, int sub_cap,
+                                                         PbPrep *__restrict__ prep, PbOut O, unsigned long long *__restrict__ prof_out)
 {
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, plast = 0;
+    if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
+#define PBS_STAMP(k) do { if constexpr (PROF) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); pt[k] += now__ - plast; plast = now__; } } while (0)
     __shared__ PbSinglesLds W;
     const int lane = threadIdx.x;
     SearchLds &L = W.s;
@@ -328,8 +332,11 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
     if (count) { const long long c = *count; nframes = c < F ? c : F; }
     const long long wave = blockIdx.x;
     if (mode != 0) {   // hand every frame on, in frame order
-        for (long long f = wave * 64 + lane; f < nframes; f += (long long)gridDim.x * 64) (mode == 1 ? listA : listB)[f] = (int)f;
-        if (wave == 0 && lane == 0) ctl[mode == 1 ? 1 : 3] = (int)nframes;
+        for (long long f = wave * 64 + lane; f < nframes; f += (long long)gridDim.x * 64) {
+            if (mode == 1) listA[(f & (kPbSub - 1)) * sub_cap + (f >> 4)] = (int)f; else listB[f] = (int)f;
+        }
+        if (wave == 0 && mode == 1 && lane < kPbSub) ctl[kPbCtlLenA + kPbCtlLine * lane] = (int)((nframes - lane + kPbSub - 1) >> 4);
+        if (wave == 0 && mode == 2 && lane == 0) ctl[kPbCtlLenB] = (int)nframes;
         return;
     }
     W.cdfH[lane] = cdf_half[lane];
@@ -337,8 +344,19 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
     wave_fence();
     for (long long f = wave; f < nframes; f += gridDim.x) {
         const long long src = index ? index[f] : f;
-        const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+        SearchFrame S;
+        if constexpr (PROF) {
+            int o1 = perm_in[f * 128 + lane], o2 = perm_in[f * 128 + 64 + lane];
+            u64 Pr = parity_in[f * 64 + lane];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(o1), "+v"(o2), "+v"(Pr));
+            PBS_STAMP(5);
+            S = search_prepare_regs(L, y, src, o1, o2, Pr, lane);
+        } else {
+            S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+        }
+        PBS_STAMP(0);
         const PbFrame Fr = pb_frame_setup(L, W.q, W.cdfA, P.c4, P.order, P.nmax, lane);
+        PBS_STAMP(1);
         pb_success_terms(W.q, W.tq, lane);
         wave_fence();
         const float best0 = tep_cost(L, 0.0f, S.d0);
@@ -360,11 +378,13 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
         bool stop2 = false;
         if (newbest) stop2 = pb_success(D, w1, W.tq, Fr);
         const u64 sm = __ballot(stop1 || stop2);
+        PBS_STAMP(2);
         if (sm == 0 && P.order > 1) {   // no rule fired on the head: the block kernel takes the frame (and what was computed for it)
             PbPrep &R = prep[f];
             R.q[lane] = W.q[lane]; R.q[lane + 64] = W.q[lane + 64];
             R.cdfA[lane] = W.cdfA[lane];
-            if (lane == 0) { R.cdfA[64] = W.cdfA[64]; R.fr = Fr; listA[atomicAdd(&ctl[1], 1)] = (int)f; }
+            if (lane == 0) { R.cdfA[64] = W.cdfA[64]; R.fr = Fr; const int sl = (int)f & (kPbSub - 1); listA[sl * sub_cap + atomicAdd(&ctl[kPbCtlLenA + kPbCtlLine * sl], 1)] = (int)f; }
+            PBS_STAMP(3);
             continue;
         }
         const int ls = sm ? __builtin_ctzll(sm) : 63;                 // (order 1 without a stop: all 64 TEPs visited)
@@ -385,7 +405,10 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
         // frontier sizes before the pops: 1, 1, 2, 3, ... (order > 1) or always 1 (order 1)
         const int ones = P.order > 1 ? (npop < 2 ? npop : 2) : npop;
         pb_write(L, S, O, f, lane, bestE, bestD, best, bestidx, sm ? npop : P.nmax, 2 * npop - ones, nev, __popcll(nbm), reason);
+        PBS_STAMP(4);
     }
+    if constexpr (PROF) { if (lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&prof_out[k], pt[k]); }
+#undef PBS_STAMP
 }
 
 // ---------------------------------------------------------------------------------------
@@ -411,6 +434,7 @@ struct __attribute__((aligned(16))) PbBlockLds {
     u64 bestD, bestE, d0;
     // per-chunk scratch
     int nkeys, bstar, degenerate, fallback, gstop, reason, ones, nev, nnb, lnb, ticket;
+    int sub, subtried, sublen[kPbSub];   // stage A: the sub-list being drained
     unsigned long long prof[24], prof_last;   // diagnostic build only (LDPC_PB_PROFILE)
 };
 
@@ -884,14 +908,17 @@ __global__ __launch_bounds__(NT, MINW) void pb_block_kernel(const float *__restr
                                                       const double *__restrict__ cdf_half,
                                                       const uchar4 *__restrict__ tab, int *__restrict__ ctl,
                                                       const int *__restrict__ listA, int *__restrict__ listB,
-                                                      int *__restrict__ listC, PbCarry *__restrict__ carry,
+                                                      int *__restrict__ listC, int sub_cap, PbCarry *__restrict__ carry,
                                                       const PbPrep *__restrict__ prep, PbOut O,
                                                       unsigned long long *__restrict__ prof_out)
 {
     __shared__ PbBlockLds<NT, CAP> B;
     SearchLds &L = B.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nlist = ctl[1];
+    // frames are drawn by ticket from the sub-lists of list A, starting with sub-list (workgroup mod 16) and moving on when
+    // one is exhausted; every sub-list has its own ticket word
+    if (tid < kPbSub) B.sublen[tid] = ctl[kPbCtlLenA + kPbCtlLine * tid];
+    if (tid == 0) { B.sub = blockIdx.x & (kPbSub - 1); B.subtried = 0; }
     const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);
     if (tid < 65) B.cdfH[tid] = cdf_half[tid];
     PbItems<NT> I;
@@ -900,11 +927,19 @@ __global__ __launch_bounds__(NT, MINW) void pb_block_kernel(const float *__restr
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) B.ticket = atomicAdd(&ctl[2], 1);
+        if (tid == 0) {
+            int tk = -1;
+            while (B.subtried < kPbSub) {
+                tk = atomicAdd(&ctl[kPbCtlTicketA + kPbCtlLine * B.sub], 1);
+                if (tk < B.sublen[B.sub]) break;
+                tk = -1; B.sub = (B.sub + 1) & (kPbSub - 1); ++B.subtried;
+            }
+            B.ticket = tk;
+        }
         __syncthreads();
         const int tk = B.ticket;
-        if (tk >= nlist) break;
-        const long long f = listA[tk];
+        if (tk < 0) break;
+        const long long f = listA[B.sub * sub_cap + tk];
         const long long src = index ? index[f] : f;
         const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, prep, tid);
         if (tid == 0) {
@@ -949,7 +984,7 @@ __global__ __launch_bounds__(NT, MINW) void pb_block_kernel(const float *__restr
             }
         }
         if (state == 2) {   // massive ties: the literal list replay decodes this frame
-            if (tid == 0) listB[atomicAdd(&ctl[3], 1)] = (int)f;
+            if (tid == 0) listB[atomicAdd(&ctl[kPbCtlLenB], 1)] = (int)f;
             continue;
         }
         if (state == 0 && done < nall) {   // no rule fired so far: the search goes on over the remaining TEPs
@@ -958,7 +993,8 @@ __global__ __launch_bounds__(NT, MINW) void pb_block_kernel(const float *__restr
                 c.lo = B.lo; c.best = B.best; c.j = B.j; c.nlive = B.nlive; c.cmp = B.cmp; c.suc1 = B.suc1; c.suc2 = B.suc2;
                 c.bestidx = B.bestidx; c.bestD = B.bestD; c.bestE = B.bestE;
                 carry[f] = c;
-                listC[atomicAdd(&ctl[5], 1)] = (int)f;
+                const int sc = (int)f & (kPbSub - 1);
+                listC[sc * sub_cap + atomicAdd(&ctl[kPbCtlLenC + kPbCtlLine * sc], 1)] = (int)f;
             }
             continue;
         }
@@ -978,7 +1014,7 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
                                                       const u64 *__restrict__ parity_in, PbParams P,
                                                       const double *__restrict__ cdf_half,
                                                       const uchar4 *__restrict__ tab, int *__restrict__ ctl,
-                                                      const int *__restrict__ listC, int *__restrict__ listB,
+                                                      const int *__restrict__ listC, int *__restrict__ listB, int sub_cap,
                                                       const PbCarry *__restrict__ carry, const PbPrep *__restrict__ prep, PbOut O,
                                                       unsigned long long *__restrict__ prof_out)
 {
@@ -989,7 +1025,12 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
     PbBlockLds<NT, CAP> &B = *reinterpret_cast<PbBlockLds<NT, CAP> *>(pb_heavy_lds);
     SearchLds &L = B.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nlist = ctl[5];
+    // tickets run over the concatenation of the 16 sub-lists of list C (a couple of thousand draws per call)
+    int cbase[kPbSub + 1];
+    cbase[0] = 0;
+#pragma unroll
+    for (int q = 0; q < kPbSub; ++q) cbase[q + 1] = cbase[q] + ctl[kPbCtlLenC + kPbCtlLine * q];
+    const int nlist = cbase[kPbSub];
     const int nall = P.order == 2 ? kPbTriples0 : kPbTabSize;
     if (tid < 65) B.cdfH[tid] = cdf_half[tid];
     PbItems<NT> I;
@@ -998,11 +1039,17 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) B.ticket = atomicAdd(&ctl[6], 1);
+        if (tid == 0) B.ticket = atomicAdd(&ctl[kPbCtlTicketC], 1);
         __syncthreads();
         const int tk = B.ticket;
         if (tk >= nlist) break;
-        const long long f = listC[tk];
+        int sc = 0;
+#pragma unroll
+        for (int q = 1; q < kPbSub; ++q) sc += tk >= cbase[q];
+        int cb = 0;
+#pragma unroll
+        for (int q = 0; q < kPbSub; ++q) cb = q == sc ? cbase[q] : cb;
+        const long long f = listC[sc * sub_cap + (tk - cb)];
         const long long src = index ? index[f] : f;
         const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, prep, tid);
         if (tid == 0) {
@@ -1034,7 +1081,7 @@ __global__ __launch_bounds__(NT) void pb_heavy_kernel(const float *__restrict__ 
         }
         __syncthreads();
         if (state == 2) {
-            if (tid == 0) listB[atomicAdd(&ctl[3], 1)] = (int)f;
+            if (tid == 0) listB[atomicAdd(&ctl[kPbCtlLenB], 1)] = (int)f;
             continue;
         }
         if (wave == 0)
@@ -1061,7 +1108,7 @@ __global__ __launch_bounds__(256) void pb_seq_kernel(const float *__restrict__ y
     const int lane = threadIdx.x & 63;
     SearchLds &L = lds[threadIdx.x >> 6];
     PbLds &B = pbl[threadIdx.x >> 6];
-    const int nlist = ctl[3];
+    const int nlist = ctl[kPbCtlLenB];
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     PbEntry *spill = spill_all + wave * spill_stride;
     B.cdfH[lane] = cdf_half[lane];
@@ -1071,7 +1118,7 @@ __global__ __launch_bounds__(256) void pb_seq_kernel(const float *__restrict__ y
     // frames are handed out through a device counter: run times differ by orders of magnitude between frames
     for (;;) {
         int fq = 0;
-        if (lane == 0) fq = atomicAdd(&ctl[4], 1);
+        if (lane == 0) fq = atomicAdd(&ctl[kPbCtlTicketB], 1);
         const int tk = __builtin_amdgcn_readfirstlane(fq);
         if (tk >= nlist) break;
         const long long f = listB[tk];
@@ -1231,7 +1278,7 @@ __global__ __launch_bounds__(256) void pb_seq_kernel(const float *__restrict__ y
 // memset node did not clear the words on the second and later replays -- ROCm 7.2 -- and the tickets ran on)
 __global__ __launch_bounds__(64) void pb_ctl_clear_kernel(int *__restrict__ ctl)
 {
-    if (threadIdx.x < kPbCtlInts) ctl[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < kPbCtlInts; i += 64) ctl[i] = 0;
 }
 
 int pb_ctx_init(ldpc_ctx *ctx)
@@ -1270,11 +1317,12 @@ static int stream_ws_pb(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int64_t sp
             return fail(LDPC_E_NOMEM, "PB-OSD control words could not be allocated");
         (void)hipFree(w.d_pb_carry); w.d_pb_carry = nullptr;
         (void)hipFree(w.d_pb_prep); w.d_pb_prep = nullptr;
-        if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * 3 * (size_t)frames) != hipSuccess ||
+        const int64_t sub_cap = (frames + kPbSub - 1) / kPbSub;
+        if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * 3 * (size_t)kPbSub * (size_t)sub_cap) != hipSuccess ||
             hipMalloc(&w.d_pb_carry, sizeof(PbCarry) * (size_t)frames) != hipSuccess ||
             hipMalloc(&w.d_pb_prep, sizeof(PbPrep) * (size_t)frames) != hipSuccess)
             return fail(LDPC_E_NOMEM, "PB-OSD frame lists for %lld frames could not be allocated", (long long)frames);
-        w.pb_cap = frames;
+        w.pb_cap = frames; w.pb_sub_cap = sub_cap;
     }
     if (grow_spill) {
         (void)hipFree(w.d_pb_spill); w.d_pb_spill = nullptr; w.pb_spill_stride = 0;
@@ -1306,30 +1354,47 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     pp.c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)p->snr_db / 10.0)));    // -4 * noise_variance, pb_testing.py:50-52
     const int mode = (p->reserved & 4) ? 2 : ((p->reserved & 2) ? 1 : 0);
     PbOut O{reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep, reinterpret_cast<int *>(p->d_aux)};
-    int *listA = w->d_pb_list, *listB = w->d_pb_list + w->pb_cap, *listC = w->d_pb_list + 2 * w->pb_cap;
+    const int64_t list_len = (int64_t)kPbSub * w->pb_sub_cap;   // >= pb_cap
+    int *listA = w->d_pb_list, *listB = w->d_pb_list + list_len, *listC = w->d_pb_list + 2 * list_len;
+    const int sub_cap = (int)w->pb_sub_cap;
     PbPrep *prep_w = reinterpret_cast<PbPrep *>(w->d_pb_prep);
     hipLaunchKernelGGL(pb_ctl_clear_kernel, dim3(1), dim3(64), 0, s, w->d_pb_ctl);
     const int64_t want = (F + 3) / 4;
     const unsigned g1 = (unsigned)(F < 1 ? 1 : (F < 32768 ? F : 32768));
-    hipLaunchKernelGGL(pb_singles_kernel, dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
-                       st->d_cdf_half, w->d_pb_ctl, listA, listB, prep_w, O);
-    const unsigned g2 = (unsigned)(F < 1024 ? F : 1024), g2b = (unsigned)(F < kPbHeavyGrid ? F : kPbHeavyGrid);
+    static const bool profile_s = getenv("LDPC_PB_PROFILE") != nullptr;
+    if (!profile_s) {
+        hipLaunchKernelGGL(pb_singles_kernel<false>, dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
+                           st->d_cdf_half, w->d_pb_ctl, listA, listB, sub_cap, prep_w, O, (unsigned long long *)nullptr);
+    } else {
+        static unsigned long long *d_ps = nullptr;
+        if (!d_ps) LDPC_HIP(hipMalloc((void **)&d_ps, sizeof(unsigned long long) * 8));
+        LDPC_HIP(hipMemsetAsync(d_ps, 0, sizeof(unsigned long long) * 8, s));
+        hipLaunchKernelGGL(pb_singles_kernel<true>, dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
+                           st->d_cdf_half, w->d_pb_ctl, listA, listB, sub_cap, prep_w, O, d_ps);
+        unsigned long long h[8];
+        LDPC_HIP(hipMemcpyAsync(h, d_ps, sizeof(h), hipMemcpyDeviceToHost, s));
+        LDPC_HIP(hipStreamSynchronize(s));
+        fprintf(stderr, "[LDPC_PB_PROFILE] singles kernel, cycles of lane 0 summed over wavefronts: start+perm/P' loads=%llu y loads+LUT=%llu frame_setup=%llu rules=%llu hand_on=%llu write=%llu\n",
+                h[5], h[0], h[1], h[2], h[3], h[4]);
+    }
+    // stage A: a multiple of 16 workgroups (one sixteenth of them per sub-list), at most the 1024 that are resident
+    const unsigned g2 = (unsigned)(F < 1024 ? ((F + kPbSub - 1) / kPbSub) * kPbSub : 1024), g2b = (unsigned)(F < kPbHeavyGrid ? F : kPbHeavyGrid);
     PbCarry *carry = reinterpret_cast<PbCarry *>(w->d_pb_carry);
     const PbPrep *prep = mode == 0 ? prep_w : nullptr;    // (cross-check routes skip the stage that fills it)
     static const bool profile = getenv("LDPC_PB_PROFILE") != nullptr;   // diagnostic build of the two workgroup kernels
     if (!profile) {
         hipLaunchKernelGGL((pb_block_kernel<256, 1024, false, 4>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, (unsigned long long *)nullptr);
+                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, sub_cap, carry, prep, O, (unsigned long long *)nullptr);
         hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, false>), dim3(g2b), dim3(1024), sizeof(PbBlockLds<1024, 4096>), s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, carry, prep, O, (unsigned long long *)nullptr);
+                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, sub_cap, carry, prep, O, (unsigned long long *)nullptr);
     } else {
         static unsigned long long *d_prof = nullptr;
         if (!d_prof) LDPC_HIP(hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 48));
         LDPC_HIP(hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 48, s));
         hipLaunchKernelGGL((pb_block_kernel<256, 1024, true, 4>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, carry, prep, O, d_prof);
+                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, sub_cap, carry, prep, O, d_prof);
         hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, true>), dim3(g2b), dim3(1024), sizeof(PbBlockLds<1024, 4096>), s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, carry, prep, O, d_prof + 24);
+                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, sub_cap, carry, prep, O, d_prof + 24);
         unsigned long long h[48];
         LDPC_HIP(hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, s));
         LDPC_HIP(hipStreamSynchronize(s));

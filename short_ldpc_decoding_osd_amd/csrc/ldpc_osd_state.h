@@ -12,15 +12,25 @@ struct StreamWs {
     unsigned char *d_perm = nullptr;  // ldpc_osd_decode: front-end results [cap][128]
     u64 *d_parity = nullptr;          //                                    [cap][64]
     int64_t cap = 0;
-    int *d_pb_ctl = nullptr;          // PB-OSD: frame tickets and list lengths (kPbCtlInts ints, zeroed per call)
-    int *d_pb_list = nullptr;         // PB-OSD: [3][pb_cap] frames handed on: list A (stage A), B (list replay), C (stage B)
+    int *d_pb_ctl = nullptr;          // PB-OSD: list lengths and tickets (kPbCtlInts ints, zeroed per call)
+    int *d_pb_list = nullptr;         // PB-OSD: [3][kPbSub * pb_sub_cap] frames handed on: list A (stage A), B (list replay), C (stage B)
     void *d_pb_carry = nullptr;       // PB-OSD: [pb_cap] search state of the frames on list C
     void *d_pb_prep = nullptr;        // PB-OSD: [pb_cap] per-frame probabilities / CDF table of the frames handed on (1 KiB each)
-    int64_t pb_cap = 0;
+    int64_t pb_cap = 0, pb_sub_cap = 0;
     void *d_pb_spill = nullptr;       // PB-OSD sequential kernel: frontier overflow [waves][stride]
     int64_t pb_spill_stride = 0;
 };
-constexpr int kPbCtlInts = 8;         // {-, list A length, ticket A, list B length, ticket B, list C length, ticket C, -}
+// A device-scope atomic on ONE word saturates at ~88 returning fetch-adds per us (MI355X_MICROARCH.md): 11 k frames
+// appended to one list through one counter kept the first PB stage at 150 us whatever else it did.  Lists A and C are
+// therefore 16 sub-lists (frame f -> sub-list f mod 16), every length on its own 128-byte line; stage A walks its
+// sub-list through that sub-list's own ticket counter and moves on to the next one when it is exhausted (a static
+// stride over the sub-list was measured: 432 instead of 398 us, the frames' run times differ too much), stage B draws
+// tickets over the concatenation of the 16.
+constexpr int kPbSub = 16, kPbCtlLine = 32;
+constexpr int kPbCtlLenA = 0, kPbCtlLenC = kPbSub * kPbCtlLine, kPbCtlLenB = 2 * kPbSub * kPbCtlLine,
+              kPbCtlTicketB = kPbCtlLenB + kPbCtlLine, kPbCtlTicketC = kPbCtlLenB + 2 * kPbCtlLine;
+constexpr int kPbCtlTicketA = kPbCtlTicketC + kPbCtlLine;   // 16 lines
+constexpr int kPbCtlInts = kPbCtlTicketA + kPbSub * kPbCtlLine;
 constexpr int kPbHeavyGrid = 512;     // grid of the stage-B PB kernel (frames are drawn by ticket)
 constexpr int kPbSeqBlocks = 64;      // grid of the sequential PB kernel (each of its 4 x 64 waves owns a spill area)
 
