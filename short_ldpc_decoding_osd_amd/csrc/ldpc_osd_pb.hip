@@ -121,7 +121,8 @@ struct PbFrame {
 
 // One wavefront: q[p] = sigmoid(c4 |y'_p|), the binomial CDF table of the mean LRB error probability and
 // the two thresholds.  L.w must be in place; q / cdfA are per-frame LDS arrays.
-__device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, double *cdfA, float c4, int order, int nmax, int lane)
+__device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, double *cdfA, float c4, int order, int nmax, int lane,
+                                                  float best0 = __builtin_inff())
 {
     q[lane] = 1.0f / (1.0f + det_expf(-(c4 * L.w[lane])));
     q[lane + 64] = 1.0f / (1.0f + det_expf(-(c4 * L.w[lane + 64])));
@@ -136,6 +137,11 @@ __device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, 
         spl = spl * (1.0f - q[p]);
     }
     const float p1 = a1 / 64.0f, lrb_mean = aw / 64.0f, pt = at / 64.0f;
+    // The rules read cdfA[beta] with beta = clamp(floor((best - sum) / lrb_mean)), best <= best0 (the order-0 metric) and
+    // sum >= 0, so entries above floor(best0 / lrb_mean) are never read (division and floor are monotone): the table's
+    // dependent float64 recurrence stops there -- typically after ~10 of its 64 steps.
+    const float bq = __builtin_floorf(best0 / lrb_mean);
+    const int ncdf = bq > 0.0f ? (bq < 64.0f ? (int)bq : 64) : 0;
     // binomial CDF tables by the pmf recurrence (float64): full table for p1, up to `order` for pt.  Lane i holds the
     // i-th coefficient; the dependent chain takes it by v_readlane (a scalar load per step sat on the critical path).
     double niu;
@@ -152,7 +158,7 @@ __device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, 
         double acc = t;
         if (lane == 0) cdfA[0] = acc;
 #pragma unroll 2
-        for (int i = 0; i < 64; ++i) {
+        for (int i = 0; i < ncdf; ++i) {
             t = t * coef(i) * ratio;
             acc = acc + t;
             if (lane == 0) cdfA[i + 1] = acc;
@@ -355,11 +361,11 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
             S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
         }
         PBS_STAMP(0);
-        const PbFrame Fr = pb_frame_setup(L, W.q, W.cdfA, P.c4, P.order, P.nmax, lane);
+        const float best0 = tep_cost(L, 0.0f, S.d0);
+        const PbFrame Fr = pb_frame_setup(L, W.q, W.cdfA, P.c4, P.order, P.nmax, lane, best0);
         PBS_STAMP(1);
         pb_success_terms(W.q, W.tq, lane);
         wave_fence();
-        const float best0 = tep_cost(L, 0.0f, S.d0);
         // lane l <-> TEP {63 - l}, visit index l; valid while its weight is below the smallest weight-2 sum
         const int p = 63 - lane;
         const float rs = L.w[p];
