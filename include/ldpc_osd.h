@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDPC_OSD_ABI_VERSION 2
+#define LDPC_OSD_ABI_VERSION 3
 
 enum {
     LDPC_OK = 0,
@@ -105,6 +105,12 @@ uint32_t ldpc_crc32c(const void *data, uint64_t len);
  * context -- from one host thread or several -- may run concurrently, for every algorithm;
  * calls on the SAME stream are ordered by the stream.  ldpc_compact needs no scratch at all.
  * (ldpc_pipeline_timing slots are shared: concurrent pipelines must use different slots.)
+ * Captured graphs: a hipGraph captured on a stream bakes in the addresses of THAT stream's workspace and
+ * may later be launched on any stream.  The graph therefore owns the capture stream's workspace: do not
+ * replay it concurrently with other work that uses the same workspace (eager calls on the capture stream,
+ * a second replay of the same or of another graph captured on that stream); the library refuses to grow
+ * (= move) a workspace once a capture has used it (LDPC_E_NOMEM: reserve enough before capturing), and
+ * ldpc_osd_release_stream frees it when the graphs are gone or the stream is destroyed.
  * ------------------------------------------------------------------------------------- */
 int ldpc_ctx_create(const ldpc_code *code, int32_t device, ldpc_ctx **out);
 void ldpc_ctx_destroy(ldpc_ctx *ctx);
@@ -153,18 +159,10 @@ int ldpc_unpack_bits(ldpc_ctx *ctx, const uint64_t *d_words, int64_t B, void *d_
  * OSD (n = 128, k = 64 codes).  Frames are addressed as d_y[ d_index ? d_index[f] : f ].
  * If d_count is non-NULL the number of frames is min(*d_count, F) read ON THE DEVICE (so a
  * compaction can feed the OSD without a host round trip); F is then the capacity.
- * The entries of d_index are frame numbers of d_y and are NOT range-checked (the entry points do not know
- * how many frames d_y holds): a caller-made list must stay inside d_y; ldpc_compact / ldpc_pipeline_run
- * write only valid, ascending frame numbers, from scratch that belongs to the call's stream.
+ * The entries of d_index are frame numbers of d_y and are NOT range-checked by default (the entry points do
+ * not know how many frames d_y holds): a caller-made list must stay inside d_y; ldpc_compact /
+ * ldpc_pipeline_run write only valid, ascending frame numbers.  Debug aid: ldpc_osd_params.y_frames.
  * ------------------------------------------------------------------------------------- */
-
-/* Pre-size OSD workspaces (640 B per frame: permutation + reduced parity rows) for up to max_frames
- * frames per ldpc_osd_decode call: the NULL stream's workspace immediately, every other stream's when it
- * is created.  Decode calls grow their stream's workspace on demand, which allocates -- so before
- * capturing calls on a stream into a hipGraph, size that stream's workspace with
- * ldpc_osd_reserve_stream (or run one eager call on it; PB-OSD needs the eager call).          */
-int ldpc_osd_reserve(ldpc_ctx *ctx, int64_t max_frames);
-int ldpc_osd_reserve_stream(ldpc_ctx *ctx, int64_t max_frames, void *stream);
 
 /* Per-frame GF(2) elimination on the device: full_gf2elim, PB_OSD/pb_testing.py:231-266.
  * d_rows_in/out: [F][64][2] u64 (row r of frame f, columns 0..127); d_swaps: [F][64][2] u8
@@ -191,12 +189,28 @@ typedef struct ldpc_osd_params {
     int32_t reserved;    /* 0; cross-check switches: bit 0 = conventional order 2 through the table-driven scan instead of
                             the register-resident kernels, bit 3 = the register-resident kernel with v_readlane
                             pairing instead of the rotation-paired persistent one; PB-OSD: bit 1 = every frame
-                            through the workgroup (sorted-chunk) kernels, bit 2 = every frame through the literal
-                            list replay                                                                       */
+                            through the sorted-chunk kernel from its first TEP, bit 2 = every frame through the
+                            literal list replay                                                               */
     void *d_aux;         /* optional DEVICE [F][4] i32, PB-OSD statistics per frame: {frontier comparisons
                             (memory_sum, pb_testing.py:122), suc counter 1 (:138), suc counter 2 (:144),
                             stop reason 0 = none / 1 = promising rule (:129) / 2 = success rule (:145)} */
+    int64_t y_frames;    /* 0 = d_index is trusted (default).  > 0 = debug bound: the number of frames d_y holds;
+                            ldpc_osd_decode / ldpc_osd_search then run on a sanitised copy of d_index (entries outside
+                            [0, y_frames) replaced by 0) and count the offenders, see ldpc_osd_index_errors           */
 } ldpc_osd_params;
+
+/* Pre-size OSD workspaces (640 B per frame: permutation + reduced parity rows) for up to max_frames
+ * frames per ldpc_osd_decode call: ldpc_osd_reserve sizes the NULL stream's workspace immediately and every
+ * other stream's when it is created.  Decode calls grow their stream's workspace on demand, which allocates
+ * -- so before capturing calls on a stream into a hipGraph, size that stream's workspace with
+ * ldpc_osd_reserve_stream: params = NULL sizes the front-end workspace only; with params it also sizes what
+ * the search of (params->algo, params->order) needs (PB-OSD: frame lists, per-frame tables, list-replay
+ * areas, ~1.1 KiB per frame + 180 MB), so that the FIRST call on the stream may be the captured one.
+ * ldpc_osd_release_stream frees the workspace of `stream` (idle, not capturing; graphs captured on it must
+ * not be launched afterwards) -- for destroyed streams, whose handle the runtime may hand out again.     */
+int ldpc_osd_reserve(ldpc_ctx *ctx, int64_t max_frames);
+int ldpc_osd_reserve_stream(ldpc_ctx *ctx, int64_t max_frames, const ldpc_osd_params *params, void *stream);
+int ldpc_osd_release_stream(ldpc_ctx *ctx, void *stream);
 
 /* Ordered-statistics decoding of F frames (front end + search).
  *   d_cw      [F][2] u64  best codeword, ORIGINAL bit order
@@ -211,6 +225,10 @@ typedef struct ldpc_osd_params {
 int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
                     const ldpc_osd_params *params, uint64_t *d_cw, float *d_metric, int32_t *d_best,
                     int32_t *d_ntep, void *stream);
+
+/* Number of d_index entries found outside [0, y_frames) by calls that carried ldpc_osd_params.y_frames > 0, since the
+ * context was created.  Synchronises the device (a debug aid, not for captured or timed regions).            */
+int ldpc_osd_index_errors(ldpc_ctx *ctx, int64_t *count);
 
 /* The search alone, on front-end results supplied by the caller (ldpc_osd_front, or any
  * (perm, P') pair: with perm = identity and d_y already in the primed order this is exactly

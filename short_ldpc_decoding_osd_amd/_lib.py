@@ -18,7 +18,7 @@ SYMBOLS = (
     "ldpc_code_get_H", "ldpc_code_get_G", "ldpc_gf2elim_host", "ldpc_tep_table", "ldpc_tep_table_fs", "ldpc_crc32c",
     "ldpc_ctx_create", "ldpc_ctx_destroy", "ldpc_ctx_nms_kernel",
     "ldpc_nms_decode", "ldpc_eval_counts", "ldpc_compact", "ldpc_pack_bits", "ldpc_unpack_bits",
-    "ldpc_osd_reserve", "ldpc_osd_reserve_stream", "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_search", "ldpc_osd_decode", "ldpc_osd_tep_eval", "ldpc_osd_counts",
+    "ldpc_osd_reserve", "ldpc_osd_reserve_stream", "ldpc_osd_release_stream", "ldpc_osd_index_errors", "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_search", "ldpc_osd_decode", "ldpc_osd_tep_eval", "ldpc_osd_counts",
     "ldpc_hosd_pattern_teps", "ldpc_hosd_front", "ldpc_hosd_search",
     "ldpc_pipeline_run", "ldpc_pipeline_timing",
 )
@@ -30,7 +30,7 @@ OSD_CONVENTIONAL, OSD_FS, OSD_PB = 0, 1, 2
 class OsdParams(C.Structure):
     _fields_ = [("order", C.c_int32), ("algo", C.c_int32), ("snr_db", C.c_float), ("fs_beta", C.c_float),
                 ("fs_tau_e", C.c_float), ("fs_tau_psc", C.c_float), ("fs_reference_quirk", C.c_int32),
-                ("reserved", C.c_int32), ("d_aux", C.c_void_p)]
+                ("reserved", C.c_int32), ("d_aux", C.c_void_p), ("y_frames", C.c_int64)]
 
 
 class Pipeline(C.Structure):
@@ -90,7 +90,9 @@ def load():
         "ldpc_pack_bits": (C.c_int, [vp, vp, i32, i64, vp, vp]),
         "ldpc_unpack_bits": (C.c_int, [vp, vp, i64, vp, i32, vp]),
         "ldpc_osd_reserve": (C.c_int, [vp, i64]),
-        "ldpc_osd_reserve_stream": (C.c_int, [vp, i64, vp]),
+        "ldpc_osd_reserve_stream": (C.c_int, [vp, i64, C.POINTER(OsdParams), vp]),
+        "ldpc_osd_release_stream": (C.c_int, [vp, vp]),
+        "ldpc_osd_index_errors": (C.c_int, [vp, pi64]),
         "ldpc_osd_ge": (C.c_int, [vp, vp, i64, vp, vp, vp, vp]),
         "ldpc_osd_front": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp]),
         "ldpc_osd_search": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, C.POINTER(OsdParams), vp, vp, vp, vp, vp]),

@@ -738,9 +738,19 @@ int osd_ctx_init(ldpc_ctx *ctx)
         LDPC_HIP(hipMalloc((void **)&st->d_cdf_half, sizeof(cdf)));
         LDPC_HIP(hipMemcpy(st->d_cdf_half, cdf, sizeof(cdf), hipMemcpyHostToDevice));
     }
+    LDPC_HIP(hipMalloc((void **)&st->d_index_errors, sizeof(unsigned long long)));
+    LDPC_HIP(hipMemset(st->d_index_errors, 0, sizeof(unsigned long long)));
     if (int rc = pb_ctx_init(ctx)) return rc;
     ctx->osd_ok = true;
     return LDPC_OK;
+}
+
+static void free_stream_ws(StreamWs &w)
+{
+    (void)hipFree(w.d_perm); (void)hipFree(w.d_parity); (void)hipFree(w.d_index_safe);
+    (void)hipFree(w.d_pb_ctl); (void)hipFree(w.d_pb_list); (void)hipFree(w.d_pb_spill); (void)hipFree(w.d_pb_prep);
+    (void)hipFree(w.d_pb_carry);
+    w = StreamWs();
 }
 
 void osd_ctx_release(ldpc_ctx *ctx)
@@ -748,14 +758,11 @@ void osd_ctx_release(ldpc_ctx *ctx)
     (void)hipFree(ctx->d_Gcols);
     (void)hipFree(ctx->d_tep);
     if (OsdState *st = state(ctx)) {
-        for (auto &kv : st->ws) {
-            (void)hipFree(kv.second.d_perm); (void)hipFree(kv.second.d_parity);
-            (void)hipFree(kv.second.d_pb_ctl); (void)hipFree(kv.second.d_pb_list); (void)hipFree(kv.second.d_pb_spill);
-            (void)hipFree(kv.second.d_pb_carry); (void)hipFree(kv.second.d_pb_prep);
-        }
+        for (auto &kv : st->ws) free_stream_ws(kv.second);
         (void)hipFree(st->d_tep_fs);
         (void)hipFree(st->d_base2);
         (void)hipFree(st->d_cdf_half);
+        (void)hipFree(st->d_index_errors);
         (void)hipFree(st->d_pb_tab);
         delete st;
     }
@@ -769,17 +776,23 @@ bool stream_capturing(hipStream_t s)
 }
 
 // the workspace of `s` with room for the front-end results of `frames` frames (0: just look it up);
-// allocation happens on a stream's first call or when a call outgrows it -- never while `s` is capturing
+// allocation happens on a stream's first call or when a call outgrows it -- never while `s` is capturing, and never
+// again once a graph was captured on `s` (the graph's nodes hold the buffer addresses: ADVICE r02)
 static int stream_ws(ldpc_ctx *ctx, hipStream_t s, int64_t frames, StreamWs **out)
 {
     OsdState *st = state(ctx);
     std::lock_guard<std::mutex> lock(st->mu);
     StreamWs &w = st->ws[s];
     if (frames > 0 && frames < st->reserve_frames) frames = st->reserve_frames;
+    const bool capturing = stream_capturing(s);
     if (frames > w.cap) {
-        if (stream_capturing(s))
+        if (capturing)
             return fail(LDPC_E_NOMEM, "OSD workspace of this stream holds %lld frames, %lld needed: run one call (or "
                         "ldpc_osd_reserve_stream) on the stream before capturing", (long long)w.cap, (long long)frames);
+        if (w.captured)
+            return fail(LDPC_E_NOMEM, "OSD workspace of this stream (%lld frames) is referenced by a captured graph and cannot grow to "
+                        "%lld: destroy the graph and call ldpc_osd_release_stream, or reserve the larger size before capturing",
+                        (long long)w.cap, (long long)frames);
         (void)hipFree(w.d_perm); (void)hipFree(w.d_parity);
         w.d_perm = nullptr; w.d_parity = nullptr; w.cap = 0;
         if (hipMalloc((void **)&w.d_perm, (size_t)frames * 128) != hipSuccess ||
@@ -787,7 +800,54 @@ static int stream_ws(ldpc_ctx *ctx, hipStream_t s, int64_t frames, StreamWs **ou
             return fail(LDPC_E_NOMEM, "OSD workspace for %lld frames could not be allocated", (long long)frames);
         w.cap = frames;
     }
+    if (capturing) w.captured = true;
     *out = &w;
+    return LDPC_OK;
+}
+
+// ldpc_osd_params.y_frames (debug aid): the frame list the kernels will follow, with every entry outside [0, y_frames)
+// replaced by 0 and counted
+__global__ __launch_bounds__(256) void index_guard_kernel(const int *__restrict__ index, const int *__restrict__ count, long long F,
+                                                          long long y_frames, int *__restrict__ safe, unsigned long long *__restrict__ errors)
+{
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < nframes; f += (long long)gridDim.x * blockDim.x) {
+        const int v = index[f];
+        const bool bad = v < 0 || v >= y_frames;
+        safe[f] = bad ? 0 : v;
+        if (bad) atomicAdd(errors, 1ull);
+    }
+}
+
+// returns the list the kernels should use: d_index itself, or its sanitised copy in the stream's workspace
+static int guarded_index(ldpc_ctx *ctx, const ldpc_osd_params *p, const int32_t *d_index, const int32_t *d_count, int64_t F, hipStream_t s,
+                         const int32_t **out)
+{
+    *out = d_index;
+    if (!d_index || p->y_frames <= 0 || F <= 0) return LDPC_OK;
+    OsdState *st = state(ctx);
+    int *safe;
+    {
+        std::lock_guard<std::mutex> lock(st->mu);
+        StreamWs &w = st->ws[s];
+        if (F > w.index_cap) {
+            if (stream_capturing(s) || w.captured)
+                return fail(LDPC_E_NOMEM, "ldpc_osd_params.y_frames: the checked frame list of this stream holds %lld entries, %lld needed; "
+                            "it cannot grow during or after a capture", (long long)w.index_cap, (long long)F);
+            (void)hipFree(w.d_index_safe); w.d_index_safe = nullptr; w.index_cap = 0;
+            if (hipMalloc((void **)&w.d_index_safe, sizeof(int) * (size_t)F) != hipSuccess)
+                return fail(LDPC_E_NOMEM, "checked frame list for %lld frames could not be allocated", (long long)F);
+            w.index_cap = F;
+        }
+        if (stream_capturing(s)) w.captured = true;
+        safe = w.d_index_safe;
+    }
+    const int64_t g = (F + 255) / 256;
+    hipLaunchKernelGGL(index_guard_kernel, dim3((unsigned)(g < 1024 ? g : 1024)), dim3(256), 0, s, d_index, d_count, (long long)F,
+                       (long long)p->y_frames, safe, st->d_index_errors);
+    LDPC_HIP(hipGetLastError());
+    *out = safe;
     return LDPC_OK;
 }
 
@@ -805,6 +865,16 @@ using namespace ldpc;
 
 extern "C" {
 
+static int check_params(ldpc_ctx *ctx, const ldpc_osd_params *p, const char *who)
+{
+    if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
+    if (p->order < 0 || p->order > 3) return fail(LDPC_E_ARG, "%s: order %d outside 0..3", who, p->order);
+    if (p->algo != LDPC_OSD_CONVENTIONAL && p->algo != LDPC_OSD_FS && p->algo != LDPC_OSD_PB)
+        return fail(LDPC_E_ARG, "%s: unknown search algorithm %d", who, p->algo);
+    if (p->algo == LDPC_OSD_PB && p->order < 1) return fail(LDPC_E_ARG, "%s: PB-OSD needs order >= 1", who);
+    return LDPC_OK;
+}
+
 int ldpc_osd_reserve(ldpc_ctx *ctx, int64_t max_frames)
 {
     if (!ctx || max_frames < 0) return fail(LDPC_E_ARG, "ldpc_osd_reserve: bad arguments");
@@ -818,12 +888,28 @@ int ldpc_osd_reserve(ldpc_ctx *ctx, int64_t max_frames)
     return stream_ws(ctx, nullptr, max_frames, &w);   // the NULL stream's workspace now; other streams on their first call
 }
 
-int ldpc_osd_reserve_stream(ldpc_ctx *ctx, int64_t max_frames, void *stream)
+int ldpc_osd_reserve_stream(ldpc_ctx *ctx, int64_t max_frames, const ldpc_osd_params *params, void *stream)
 {
     if (!ctx || max_frames < 0) return fail(LDPC_E_ARG, "ldpc_osd_reserve_stream: bad arguments");
     if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
     StreamWs *w;
-    return stream_ws(ctx, (hipStream_t)stream, max_frames, &w);
+    int rc = stream_ws(ctx, (hipStream_t)stream, max_frames, &w);
+    if (rc || !params) return rc;
+    if ((rc = check_params(ctx, params, "ldpc_osd_reserve_stream"))) return rc;
+    if (params->algo == LDPC_OSD_PB && max_frames > 0) return pb_reserve(ctx, (hipStream_t)stream, max_frames, params->order);
+    return LDPC_OK;
+}
+
+int ldpc_osd_release_stream(ldpc_ctx *ctx, void *stream)
+{
+    if (!ctx) return fail(LDPC_E_ARG, "ldpc_osd_release_stream: null ctx");
+    OsdState *st = state(ctx);
+    if (!st) return LDPC_OK;
+    if (stream_capturing((hipStream_t)stream)) return fail(LDPC_E_ARG, "ldpc_osd_release_stream: the stream is capturing");
+    std::lock_guard<std::mutex> lock(st->mu);
+    auto it = st->ws.find((hipStream_t)stream);
+    if (it != st->ws.end()) { free_stream_ws(it->second); st->ws.erase(it); }
+    return LDPC_OK;
 }
 
 int ldpc_osd_ge(ldpc_ctx *ctx, const uint64_t *d_rows_in, int64_t F, uint64_t *d_rows_out, uint8_t *d_swaps,
@@ -849,16 +935,6 @@ int ldpc_osd_front(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, cons
                        (long long)F, reinterpret_cast<const u64 *>(ctx->d_Gcols), d_perm, reinterpret_cast<u64 *>(d_parity),
                        d_nswaps);
     LDPC_HIP(hipGetLastError());
-    return LDPC_OK;
-}
-
-static int check_params(ldpc_ctx *ctx, const ldpc_osd_params *p, const char *who)
-{
-    if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
-    if (p->order < 0 || p->order > 3) return fail(LDPC_E_ARG, "%s: order %d outside 0..3", who, p->order);
-    if (p->algo != LDPC_OSD_CONVENTIONAL && p->algo != LDPC_OSD_FS && p->algo != LDPC_OSD_PB)
-        return fail(LDPC_E_ARG, "%s: unknown search algorithm %d", who, p->algo);
-    if (p->algo == LDPC_OSD_PB && p->order < 1) return fail(LDPC_E_ARG, "%s: PB-OSD needs order >= 1", who);
     return LDPC_OK;
 }
 
@@ -922,6 +998,7 @@ int osd_search_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, 
     int rc = check_params(ctx, p, "ldpc_osd_search");
     if (rc) return rc;
     if (F == 0) return LDPC_OK;
+    if ((rc = guarded_index(ctx, p, d_index, d_count, F, s, &d_index))) return rc;
     bool fused = false;
     rc = launch_search(ctx, d_y, d_index, d_count, F, d_perm, reinterpret_cast<const u64 *>(d_parity), p, d_cw, d_metric, d_best, d_ntep,
                        s, d_label, d_counts, &fused);
@@ -941,6 +1018,7 @@ int ldpc_osd_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
     int rc = check_params(ctx, p, "ldpc_osd_search");
     if (rc) return rc;
     if (F == 0) return LDPC_OK;
+    if ((rc = guarded_index(ctx, p, d_index, d_count, F, (hipStream_t)stream, &d_index))) return rc;
     return launch_search(ctx, d_y, d_index, d_count, F, d_perm, reinterpret_cast<const u64 *>(d_parity), p, d_cw, d_metric,
                          d_best, d_ntep, (hipStream_t)stream);
 }
@@ -956,9 +1034,22 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
     hipStream_t s = (hipStream_t)stream;
     StreamWs *w;
     if ((rc = stream_ws(ctx, s, F, &w))) return rc;
+    if ((rc = guarded_index(ctx, p, d_index, d_count, F, s, &d_index))) return rc;
     hipLaunchKernelGGL(osd_front_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
                        reinterpret_cast<const u64 *>(ctx->d_Gcols), w->d_perm, w->d_parity, (int *)nullptr);
     return launch_search(ctx, d_y, d_index, d_count, F, w->d_perm, w->d_parity, p, d_cw, d_metric, d_best, d_ntep, s);
+}
+
+int ldpc_osd_index_errors(ldpc_ctx *ctx, int64_t *count)
+{
+    if (!ctx || !count) return fail(LDPC_E_ARG, "ldpc_osd_index_errors: null argument");
+    *count = 0;
+    OsdState *st = state(ctx);
+    if (!st || !st->d_index_errors) return LDPC_OK;
+    unsigned long long v = 0;
+    LDPC_HIP(hipMemcpy(&v, st->d_index_errors, sizeof(v), hipMemcpyDeviceToHost));   // (synchronises the device)
+    *count = (int64_t)v;
+    return LDPC_OK;
 }
 
 int ldpc_osd_tep_eval(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,

@@ -20,15 +20,13 @@
 // the sequential rules are recovered with prefix scans and a "first stop" reduction.
 //
 //   pb_singles_kernel  one frame per wavefront: the pop sequence starts with the weight-1 TEPs {63}, {62}, ...
-//                      while |y'_p| < |y'_62| + |y'_63| (the smallest weight-2 sum); one TEP per lane.  About
-//                      half of the frames stop here at 2.5 dB; the others are appended to list A.
-//   pb_block_kernel    one frame of list A per 256-thread workgroup, restarted from its first TEP: two chunks of ~768
-//                      TEPs (capacity 1024), each = the members of a sum range generated directly from the sorted
-//                      reliabilities (PbItems: no table pass), its upper bound chosen by pb_pick_bound; bucket rank sort
-//                      in LDS; exact tie repair; parallel evaluation; sequential rules by prefix scans.  96 % of the
-//                      frames stop here; the rest go to list C with their search state, massive ties to list B.
-//   pb_heavy_kernel    one frame of list C per 1024-thread workgroup: chunks of ~3072 TEPs (capacity 4096) until a
-//                      rule fires or all N_max TEPs are visited.
+//                      while |y'_p| < |y'_62| + |y'_63| (the smallest weight-2 sum); one TEP per lane.  Two thirds
+//                      of the frames stop here at 2.5 dB; the others are appended to list A.
+//   pb_wave_kernel     one frame of list A per WAVEFRONT (round 3; rounds 1-2 used 256- and 1024-thread workgroups),
+//                      restarted from its first TEP and taken to its stop: chunks of <= 512 TEPs, each = the members of a
+//                      sum range walked directly from the sorted reliabilities (no table, no binary searches); bucket
+//                      rank sort in LDS; exact tie repair; parallel evaluation; sequential rules by prefix scans.  No
+//                      workgroup barrier anywhere.  Massive ties go to list B.
 //   pb_seq_kernel      the literal list replay (round-1 kernel) for list B.
 #include <math.h>
 #include <stdio.h>
@@ -81,7 +79,8 @@ struct __attribute__((aligned(16))) PbLds {
 
 struct PbParams {
     int order, nmax;
-    int t1, t2, t3;              // chunk targets: stage A first / second chunk, stage B
+    int t1, t2;                  // chunk targets: first chunk / later chunks
+    int t3, budget;              // chunk target of the latency-shaped kernel; TEPs after which a frame may be handed to it
     float c4;
     long long cmin_off;          // offset of the spilled chunk minima inside a wave's global area
 };
@@ -120,19 +119,19 @@ struct PbFrame {
 };
 
 // One wavefront: q[p] = sigmoid(c4 |y'_p|), the binomial CDF table of the mean LRB error probability and
-// the two thresholds.  L.w must be in place; q / cdfA are per-frame LDS arrays.
-__device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, double *cdfA, float c4, int order, int nmax, int lane,
+// the two thresholds.  w = |y'| (LDS) must be in place; q / cdfA are per-frame LDS arrays.
+__device__ __forceinline__ PbFrame pb_frame_setup(const float *w, float *q, double *cdfA, float c4, int order, int nmax, int lane,
                                                   float best0 = __builtin_inff())
 {
-    q[lane] = 1.0f / (1.0f + det_expf(-(c4 * L.w[lane])));
-    q[lane + 64] = 1.0f / (1.0f + det_expf(-(c4 * L.w[lane + 64])));
+    q[lane] = 1.0f / (1.0f + det_expf(-(c4 * w[lane])));
+    q[lane + 64] = 1.0f / (1.0f + det_expf(-(c4 * w[lane + 64])));
     wave_fence();
     // sequential (ascending position) means / product, as the oracle defines them
     float a1 = 0.0f, aw = 0.0f, at = 0.0f, spl = 1.0f;
 #pragma unroll 4
     for (int p = 0; p < 64; ++p) {
         a1 = a1 + q[64 + p];
-        aw = aw + L.w[64 + p];
+        aw = aw + w[64 + p];
         at = at + q[p];
         spl = spl * (1.0f - q[p]);
     }
@@ -179,8 +178,22 @@ __device__ __forceinline__ PbFrame pb_frame_setup(const SearchLds &L, float *q, 
 }
 
 // promising-probability rule (acquire_prob_promising :448-461): true = stop
-__device__ __forceinline__ bool pb_not_promising(float rs, float best, const PbFrame &F, float c4, const double *cdfA,
-                                                 const double *cdfH, float &w1_out)
+// (cdfA / cdfH: float64 tables, or the same tables already rounded to float32 -- they are only read through the cast)
+template <typename TA>
+__device__ __forceinline__ float pb_promising_bs(float rs, float best, const PbFrame &F, float c4, const TA *cdfA, const TA *cdfH, float &w1_out)
+{
+    const float w1 = det_expf(c4 * rs) * F.spl, w2 = 1.0f - w1;
+    const float bt = __builtin_floorf((best - rs) / F.lrb_mean);
+    const int beta = bt > 0.0f ? (bt < 64.0f ? (int)bt : 64) : 0;
+    float bs = 0.0f;
+    bs = bs + w1 * (float)cdfA[beta];
+    bs = bs + w2 * (float)cdfH[beta];
+    w1_out = w1;
+    return bs;
+}
+template <typename TA>
+__device__ __forceinline__ bool pb_not_promising(float rs, float best, const PbFrame &F, float c4, const TA *cdfA,
+                                                 const TA *cdfH, float &w1_out)
 {
     const float w1 = det_expf(c4 * rs) * F.spl, w2 = 1.0f - w1;
     const float bt = __builtin_floorf((best - rs) / F.lrb_mean);
@@ -214,20 +227,12 @@ __device__ __forceinline__ bool pb_success(u64 D, float w1, const float2 *tq, co
     return (double)p_suc > F.p_t_suc;
 }
 
-// ---------------------------------------------------------------------------------------
-// TEP table of the chunk kernels: ids 0..63 = {63 - id}; ids 64..2079 = pairs, 2080..43743 = triples, each
-// class by DESCENDING smallest position, so "all positions >= a" is a prefix of every class.
-// ---------------------------------------------------------------------------------------
+// number of TEPs of weight 1, 1..2, 1..3 over 64 positions
 constexpr int kPbPairs0 = 64, kPbTriples0 = 64 + 2016, kPbTabSize = 64 + 2016 + 41664;
 
 struct PbTep {
     int p0, p1, p2, wt;
 };
-__device__ __forceinline__ PbTep pb_tep(const uchar4 *__restrict__ tab, int id)
-{
-    const uchar4 t = tab[id];
-    return PbTep{t.x, t.y, t.z, t.w};
-}
 __device__ __forceinline__ float pb_sum(const float *w, const PbTep &t)
 {
     float s = w[t.p0];
@@ -289,6 +294,10 @@ struct PbPrep {
     double cdfA[65];
     float q[128];
     PbFrame fr;
+    // the search state after the weight-1 head of the pop sequence (no rule fired on it): the chunk kernel goes on from here
+    float hbest;
+    int nhead, hsuc2, hbestidx;
+    u64 hbestD, hbestE;
 };
 __device__ __forceinline__ void pb_write(SearchLds &L, const SearchFrame &S, const PbOut &O, long long f, int lane, u64 bestE,
                                          u64 bestD, float best, int bestidx, int ntep, int cmp, int suc1, int suc2, int stop)
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
         }
         PBS_STAMP(0);
         const float best0 = tep_cost(L, 0.0f, S.d0);
-        const PbFrame Fr = pb_frame_setup(L, W.q, W.cdfA, P.c4, P.order, P.nmax, lane, best0);
+        const PbFrame Fr = pb_frame_setup(L.w, W.q, W.cdfA, P.c4, P.order, P.nmax, lane, best0);
         PBS_STAMP(1);
         pb_success_terms(W.q, W.tq, lane);
         wave_fence();
@@ -389,6 +398,18 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
             PbPrep &R = prep[f];
             R.q[lane] = W.q[lane]; R.q[lane + 64] = W.q[lane + 64];
             R.cdfA[lane] = W.cdfA[lane];
+            {   // the head's result: nhead TEPs popped and evaluated, the last improvement among them (if any)
+                const u64 nbm = __ballot(newbest);
+                float hb = best0;
+                u64 hD = S.d0, hE = 0;
+                int hidx = 0;
+                if (nbm) {
+                    const int lb = 63 - __builtin_clzll(nbm);
+                    hb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cost), lb));
+                    hD = readlane64(D, lb); hE = 1ull << (63 - lb); hidx = lb + 1;
+                }
+                if (lane == 0) { R.hbest = hb; R.nhead = nhead; R.hsuc2 = __popcll(nbm); R.hbestidx = hidx; R.hbestD = hD; R.hbestE = hE; }
+            }
             if (lane == 0) { R.cdfA[64] = W.cdfA[64]; R.fr = Fr; const int sl = (int)f & (kPbSub - 1); listA[sl * sub_cap + atomicAdd(&ctl[kPbCtlLenA + kPbCtlLine * sl], 1)] = (int)f; }
             PBS_STAMP(3);
             continue;
@@ -418,9 +439,988 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// stage 2: one frame per workgroup, sorted chunks
+// stage 2: sorted chunks of the visit order, ONE FRAME PER WAVEFRONT (round 3)
+//
+// Round 2 ran this stage on 256- and 1024-thread workgroups: ~17 workgroup barriers per chunk, ~15 wave
+// instructions per TEP, 60 % of the wave-cycles waiting (profiles/r03/pmc_counters_nms10_pb3_snr1.0_baseline_*).
+// Here a frame belongs to ONE wavefront from its first chunk to its stop: no barrier anywhere (phases are
+// separated by wave fences), the frame's search state lives in registers, ~9 frames are resident per CU and
+// the dispatcher balances them (one wavefront per workgroup, compile-time LDS addresses).
+//
+// Direct enumeration of a sum range.  The MRB positions are sorted by reliability (w[0] >= w[1] >= ...) and float
+// addition is monotone, so with the other positions fixed the sum of a TEP is non-increasing in its LAST position m.
+// The TEPs are 2017 "items" -- the singles {m}; the pairs {i, m} of one i; the triples {i, j, m} of one (i, j) --
+// inside each of which the members appear in the visit order by DESCENDING m.  Every lane owns 32 items:
+//   q = 0..30  triples, row pair q: lanes l < 62 - q own (i, j) = (q, q + 1 + l), lanes 62 - q .. 62 own (61 - q, l)
+//              (rows q and 61 - q hold 62 - q and q + 1 items: 63 together; lane 63 owns none)
+//   q = 31     lanes 0..62: the pairs of i = l;  lane 63: the singles
+// and keeps per item, in registers: the sum of its fixed positions, a cursor (members [cursor, 64) are visited) and the
+// sum of its NEXT member.  The chunk (lo, T] is produced by a WALK: for each q, while any lane's next member is <= T
+// those lanes emit it (key = sum bits << 32 | positions; slot = running count + mbcnt of the ballot) and step their
+// cursor.  An item costs one compare when it has nothing to give, the members cost one trip each; no binary searches,
+// no count-then-write double pass, no block scan.  T can be ANY value -- exactness does not depend on it -- so it is
+// sized to the work: first guess from pb_bound_guess / the growth exponent of the last two bounds, a short chunk is
+// extended in place (the walk resumes), an overflowing walk is abandoned and retried with a smaller T.
 // ---------------------------------------------------------------------------------------
 constexpr int kPbMaxTie = 16;
+constexpr int kPbWaveCap = 512;   // chunk capacity of the chunk kernel
+
+template <int CAP>
+struct __attribute__((aligned(16))) PbWaveLds {
+    float tail[4][17];        // tail[g][c] <= the sum of the c lightest parity weights of quarter g (pbw_cost_floor)
+    u64 P[64];                // rows of P'
+    float w[128];             // |y'|
+    float2 tq[64];            // success-rule factors (pb_success_terms)
+    float cdfA[68], cdfH[68]; // the two binomial CDF tables ROUNDED TO float32 -- the rules only ever read them through a
+                              // (float) cast (pb_not_promising), so storing the rounded value is the same arithmetic
+    // the chunk: as walked (slots 0..n-1), then -- skewed, one pad entry per eight: lane-consecutive 64-bit accesses
+    // would otherwise fall on two LDS banks -- grouped by bucket and finally in visit order; 64 entries of slack take the
+    // overshoot of the walk's last trip and the "never before me" pad of the rank count
+    u64 keys[(CAP + 64) + (CAP + 64) / 8];
+    union {
+        int hist[CAP];        // bucket counts, then cursors; the costs of a chunk
+        unsigned list[CAP + 64];   // the walk's work list (one entry per member emitted)
+    };
+    unsigned cur[8][64];      // tentative cursors of the walk: byte q & 3 of cur[q / 4][lane] = item q of that lane
+    u64 ck[16], rk[16];       // sort-free chunk pass: improvement candidates / the records among them (key, cost)
+    float cc[16], rc[16];
+    u64 cw[2];
+};
+
+__device__ __forceinline__ int pbw_phys(int i) { return i + (i >> 3); }
+
+// The weighted distance of a candidate, two ways.  The chunk kernel keeps no byte LUT (8 KiB of LDS per frame: with it two
+// wavefronts fit a SIMD, without it three to four, and the kernel spends half its time waiting):
+//   pbw_cost_floor  a LOWER bound from the NUMBER of parity discrepancies in each quarter of the parity part: the candidate
+//                   differs from the hard decisions in popcount(D_g) positions of quarter g, which weigh at least as much as
+//                   that quarter's popcount(D_g) lightest positions.  The rules need a cost only to know whether it beats
+//                   the best so far; past the first chunk the bound settles that for all but ~1 key in 10^3..10^4 (measured
+//                   on NMS failures: 0.01 % at 1.0 dB, 0.06 % at 2.5 dB; one popcount over all 64 positions lets 13-17 %
+//                   through: a random D has ~32 ones, and the 32 lightest weights are light).  Rounded down twice (table
+//                   entries, then the sum) so that it stays below the float32 value of the canonical summation, whose
+//                   rounding errors are < 1e-6 relative.
+//   pbw_cost_exact  the canonical order of the byte LUT (each byte ascending from 0, bytes added in order; tep_cost),
+//                   64 conditional adds: bit-identical to the LUT form.  For the survivors of the bound.
+template <int CAP>
+__device__ __forceinline__ float pbw_cost_floor(const PbWaveLds<CAP> &L, float mrb, u64 D)
+{
+    const unsigned lo = (unsigned)D, hi = (unsigned)(D >> 32);
+    const float t0 = L.tail[0][__popc(lo & 0xFFFFu)], t1 = L.tail[1][__popc(lo >> 16)];
+    const float t2 = L.tail[2][__popc(hi & 0xFFFFu)], t3 = L.tail[3][__popc(hi >> 16)];
+    return (((mrb + t0) + t1) + (t2 + t3)) * 0.99999f;
+}
+template <int CAP>
+__device__ __forceinline__ float pbw_cost_exact(const PbWaveLds<CAP> &L, float mrb, u64 D)
+{
+    float acc = mrb;
+#pragma unroll 1
+    for (int b = 0; b < 8; ++b) {
+        const unsigned v = (unsigned)(D >> (8 * b)) & 255u;
+        float bs = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bs = ((v >> t) & 1u) ? bs + L.w[64 + 8 * b + t] : bs;
+        acc = acc + bs;
+    }
+    return acc;
+}
+// cost if it can be below `bound`, +inf otherwise (exact for every use: the rules only compare costs with bests <= bound)
+template <int CAP>
+__device__ __forceinline__ float pbw_cost(const PbWaveLds<CAP> &L, float mrb, u64 D, float bound)
+{
+    float c = __builtin_inff();
+    if (pbw_cost_floor<CAP>(L, mrb, D) < bound) c = pbw_cost_exact<CAP>(L, mrb, D);
+    return c;
+}
+
+// positions of a key's low word: p0 | p1 << 8 | p2 << 16 | weight << 24 (ascending positions, unused = 0)
+__device__ __forceinline__ PbTep pbw_tep(unsigned code)
+{
+    return PbTep{(int)(code & 255u), (int)((code >> 8) & 255u), (int)((code >> 16) & 255u), (int)(code >> 24)};
+}
+
+// the items of a lane (see above).  base: the members are m in (base, 63]; code / sh: a member's key is code | m << sh
+struct PbwItem {
+    int i, j, base, sh;
+    unsigned code;
+};
+__device__ __forceinline__ PbwItem pbw_item(int q, int lane)
+{
+    // (opaque copy of the lane number: otherwise the compiler hoists the 32 items' constants out of every loop and keeps
+    //  ~100 VGPRs alive for the whole kernel; they cost three or four instructions where they are needed)
+    asm volatile("" : "+v"(lane));
+    PbwItem it;
+    if (q < 31) {
+        const bool first = lane < 62 - q;
+        it.i = first ? q : 61 - q;
+        it.j = first ? q + 1 + lane : lane;
+        it.base = lane <= 62 ? it.j : 63;
+        it.code = (3u << 24) | ((unsigned)it.j << 8) | (unsigned)it.i;
+        it.sh = 16;
+    } else {
+        it.i = lane; it.j = lane;
+        it.base = lane <= 62 ? lane : -1;
+        it.code = lane <= 62 ? ((2u << 24) | (unsigned)lane) : (1u << 24);
+        it.sh = lane <= 62 ? 8 : 0;
+    }
+    return it;
+}
+
+// In-kernel stamps of the diagnostic instantiation (PROF = true, launched only when LDPC_PB_PROFILE is set): the shader
+// clock since the previous stamp is added to slot k.  The product instantiation contains none of this.
+enum { kPwSetup = 0, kPwWalk, kPwSort, kPwTie, kPwEval, kPwRules, kPwCombine, kPwFinish, kPwFrames, kPwChunks, kPwWalks, kPwKeys,
+       kPwSweepA, kPwSweepB, kPwDense, kPwRounds, kPwTrips, kPwScan, kPwSorted, kPwLoad1, kPwLoad2, kPwStore, kPwSlots };
+#define PBW_STAMP(k) do { if constexpr (PROF) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); pt[k] += now__ - plast; plast = now__; } } while (0)
+
+// Walk state.  Registers: for each of the lane's 32 items the sum of its NEXT member (NaN: exhausted) and the COMMITTED
+// cursors (one byte per item, four items per register; members [cursor, 64) are visited).  LDS: the TENTATIVE cursors
+// L.cur[q / 4][lane] of the chunk being sized -- in the dense phase below a lane works on whatever item the list hands it.
+struct PbWalk {
+    float nxt[32];
+    unsigned ecur[8];
+};
+
+__device__ __forceinline__ float pbw_nan() { return __int_as_float(0x7FC00000); }
+
+template <int CAP>
+__device__ __forceinline__ void pbw_cursors_store(PbWaveLds<CAP> &L, const unsigned (&cur)[8], int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) L.cur[k][lane] = cur[k];
+}
+template <int CAP>
+__device__ __forceinline__ void pbw_cursors_load(const PbWaveLds<CAP> &L, unsigned (&cur)[8], int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cur[k] = L.cur[k][lane];
+}
+
+template <int CAP>
+__device__ __forceinline__ void pbw_walk_init(PbWaveLds<CAP> &L, PbWalk &W, int order, int lane)
+{
+    const float *w = L.w;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const PbwItem it = pbw_item(q, lane);
+        const float sb = q < 31 ? w[it.i] + w[it.j] : (lane <= 62 ? w[lane] : 0.0f);
+        const bool live = it.base < 63 && (q < 31 ? order > 2 : (order > 1 || lane == 63));
+        W.nxt[q] = live ? sb + w[63] : pbw_nan();
+        if ((q & 3) == 3) asm volatile("" ::: "memory");   // (keeps the scheduler from issuing all 64 reads at once: registers)
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) W.ecur[k] = 0x40404040u;
+    pbw_cursors_store<CAP>(L, W.ecur, lane);
+}
+
+// Emit every member with sum <= T that lies beyond the tentative cursors; returns the new running count (> CAP: the chunk
+// overflowed, the walk stopped early and W.nxt still describes the cursors the walk STARTED from -- the caller puts those
+// back).  Three phases:
+//   list    one compare per item: the items whose next member is <= T are appended to a work list (ballot + mbcnt, no loop);
+//           86 % of the items have nothing to give and cost that compare;
+//   dense   the list, 64 entries per trip, every lane emits exactly ONE member of its entry's item (key = sum bits << 32 |
+//           positions; slot = running count + mbcnt), steps that item's cursor in LDS and, if the item's next member is
+//           <= T too, appends the entry to the list's tail again -- so a trip runs at full lanes whatever the items' lengths;
+//           an item that is done leaves its new next-member sum in the list slot it first occupied;
+//   collect the owners take those sums back (same ballots, same slots; branch-free).
+// A lane works on whatever item the list hands it, hence the cursors in LDS and the item geometry from run-time (q, lane).
+// (Round 3's first form walked every item to its end where it stood -- while any lane has a member, emit --: ~80 trips per
+//  chunk at ~10 % of the lanes, 28 k of a chunk's 55 k cycles; the second listed only the items with a second member:
+//  2100 vector instructions per walk, this form ~800.)
+template <int CAP, bool PROF>
+__device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, PbWalk &W, float T, int cnt, int order, int lane,
+                                        unsigned long long (&pt)[kPwSlots])
+{
+    unsigned long long plast = 0;
+    if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
+    unsigned *const list = L.list;      // entry: q | owner lane << 5 | first slot << 11
+    int tail = 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        if (q < 31 && order < 3) continue;
+        const bool pend = W.nxt[q] <= T;
+        const u64 act = tail <= CAP ? __ballot(pend) : 0ull;      // (more than CAP pending items: an overflow already)
+        if (act) {
+            const int p = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+            if (pend) list[p] = (unsigned)q | ((unsigned)lane << 5) | ((unsigned)p << 11);
+            tail += __popcll(act);
+        }
+    }
+    PBW_STAMP(kPwSweepA);
+    if (tail == 0) return cnt;
+    if (tail > CAP) return CAP + 1;
+    wave_fence();
+    int head = 0;
+    while (head < tail && cnt <= CAP) {
+        if constexpr (PROF) pt[kPwTrips] += 1;
+        const int e = head + lane;
+        const bool has = e < tail;
+        const unsigned ent = has ? list[e] : 0u;
+        const int q = (int)(ent & 31u), l = (int)((ent >> 5) & 63u);
+        int i, j, base, sh;
+        unsigned code;
+        if (q < 31) {
+            const bool first = l < 62 - q;
+            i = first ? q : 61 - q; j = first ? q + 1 + l : l; base = j; sh = 16;
+            code = (3u << 24) | ((unsigned)j << 8) | (unsigned)i;
+        } else {
+            i = l; j = l; base = l <= 62 ? l : -1; sh = l <= 62 ? 8 : 0;
+            code = l <= 62 ? ((2u << 24) | (unsigned)l) : (1u << 24);
+        }
+        unsigned char *const cb = reinterpret_cast<unsigned char *>(&L.cur[q >> 2][l]) + (q & 3);
+        const int a = has ? (int)*cb : 1;
+        const float sbv = q < 31 ? L.w[i] + L.w[j] : (l <= 62 ? L.w[l] : 0.0f);
+        const int m = a - 1;
+        const float s = sbv + L.w[m], sn = sbv + L.w[m > 0 ? m - 1 : 0];
+        const float nx = m > base + 1 ? sn : pbw_nan();
+        const u64 act = __ballot(has);
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, (unsigned)cnt));
+        const bool again = has && nx <= T;
+        const u64 more = __ballot(again);
+        const int nt = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(more >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)more, 0u));
+        wave_fence();                    // (every lane has read its entry: the slots may be written now)
+        if (has) {
+            L.keys[pos] = ((u64)__float_as_uint(s) << 32) | (code | ((unsigned)m << sh));
+            *cb = (unsigned char)m;
+            if (again) list[nt] = ent; else list[ent >> 11] = __float_as_uint(nx);
+        }
+        cnt += __popcll(act);
+        head = head + 64 < tail ? head + 64 : tail;
+        tail += __popcll(more);
+        wave_fence();
+        if (tail > CAP) { cnt = CAP + 1; break; }   // every entry ever listed is one member: more than CAP members, an overflow
+    }
+    PBW_STAMP(kPwDense);
+    if (cnt > CAP) return cnt;
+    // collect: the same ballots as above give every owner the slots of its items
+    int slot0 = 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        if (q < 31 && order < 3) continue;
+        const bool pend = W.nxt[q] <= T;
+        const u64 act = __ballot(pend);
+        const int p = slot0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+        const float v = __uint_as_float(list[p]);       // (a lane without a pending item reads some slot and drops it)
+        W.nxt[q] = pend ? v : W.nxt[q];
+        slot0 += __popcll(act);
+    }
+    PBW_STAMP(kPwSweepB);
+    return cnt;
+}
+
+// Typical bound of the N smallest sums in units of the smallest triple sum m3 = w61 + w62 + w63 (medians over decoding
+// failures at 2.5 dB; the ratio is scale-free and tight: +-6 % between the 10th and 90th percentile, where the count
+// changes like the ~6th power of the bound).  Only a first guess: pbw_next_chunk corrects it with exact counts.
+__device__ __forceinline__ float pb_bound_guess(float n)
+{
+    const float l = __builtin_amdgcn_logf(n < 64.0f ? 64.0f : n);
+    const float x[8] = {8.0f, 9.0f, 10.0f, 11.0f, 12.0f, 13.0f, 14.2877f, 15.4168f};     // log2 of 256 ... 20000, 43744
+    const float g[8] = {0.80f, 0.89f, 1.02f, 1.14f, 1.23f, 1.33f, 1.52f, 2.2f};
+    if (l <= x[0]) return g[0] * __builtin_amdgcn_exp2f((l - x[0]) / 6.0f);
+    float r = g[7];
+#pragma unroll
+    for (int k = 6; k >= 0; --k) if (l <= x[k + 1]) r = g[k] + (g[k + 1] - g[k]) * (l - x[k]) / (x[k + 1] - x[k]);
+    return r;
+}
+
+// The next chunk: walks (lo, T] for a T aimed at `target` members, 0 < n <= CAP.  Returns n and T; the chunk's keys are
+// L.keys[0..n) and the walk's cursors are committed.  -1: the range cannot be split (massively equal sums: the frame goes
+// to the list replay); 0: nothing is left to visit (NaN sums).
+template <int CAP, bool PROF>
+__device__ __forceinline__ int pbw_next_chunk(PbWaveLds<CAP> &L, PbWalk &W, int order, float lo, int done, int nall, int target, int lane,
+                                              float &Tout, float &tprev, float &nprev, int &nwalks, unsigned long long (&pt)[kPwSlots])
+{
+    const float inf = __builtin_inff();
+    const float *w = L.w;
+    const float m3 = (w[61] + w[62]) + w[63];
+    const float want = (float)(done + target);
+    float Tl = lo, Th = inf;
+    float T = nall - done <= CAP ? inf : m3 * pb_bound_guess(want);
+    if (tprev > 0.0f && nprev > 0.0f && lo > tprev && (float)done > nprev && T < inf) {   // growth exponent of the last two bounds
+        const float pe = (__builtin_amdgcn_logf((float)done) - __builtin_amdgcn_logf(nprev)) / (__builtin_amdgcn_logf(lo) - __builtin_amdgcn_logf(tprev));
+        if (pe > 1.5f && pe < 20.0f) T = lo * __builtin_amdgcn_exp2f((__builtin_amdgcn_logf(want) - __builtin_amdgcn_logf((float)done)) / pe);
+    }
+    if (!(T > lo)) T = lo > 0.0f ? lo * 1.05f : w[0];
+    float tp = lo, np_ = (float)done;        // last point with a known count
+    int cnt = 0, c_ok = 0;
+    float T_ok = lo;
+    unsigned a_ok[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int it = 0; it < 48; ++it) {
+        cnt = pbw_walk<CAP, PROF>(L, W, T, cnt, order, lane, pt);
+        ++nwalks;
+        bool over = false;
+        if (cnt > CAP) {
+            if (c_ok > 0) break;
+            over = true;
+            Th = T;
+            pbw_cursors_store<CAP>(L, W.ecur, lane);      // back to the committed cursors
+            cnt = 0;
+        } else if (cnt > 0 && (!(T < inf) || 5 * cnt >= 2 * target || it >= 3)) {
+            c_ok = cnt; T_ok = T;
+            break;
+        } else if (!(T < inf)) {
+            return 0;                         // everything that can be visited has been
+        } else {                              // too few so far: keep them and walk on from here
+            if (cnt > 0) {
+                c_ok = cnt; T_ok = T;
+                pbw_cursors_load<CAP>(L, a_ok, lane);
+            }
+            Tl = T;
+        }
+        float Tn;
+        if (over) {
+            Tn = Tl > 0.0f ? Tl + (Th - Tl) * 0.5f : Th * 0.9f;
+        } else {
+            const float tot = (float)(done + cnt);
+            float p = 6.0f;
+            if (tp > 0.0f && np_ > 0.0f && tot != np_ && T != tp) {
+                const float pe = (__builtin_amdgcn_logf(tot) - __builtin_amdgcn_logf(np_)) / (__builtin_amdgcn_logf(T) - __builtin_amdgcn_logf(tp));
+                if (pe > 1.5f && pe < 20.0f) p = pe;
+            }
+            if (cnt > 0) { tp = T; np_ = tot; }
+            Tn = cnt > 0 ? T * __builtin_amdgcn_exp2f((__builtin_amdgcn_logf(want) - __builtin_amdgcn_logf(tot)) / p) : T * 1.1f;
+            if (it >= 6 || !(Tn > Tl) || !(Tn < Th)) Tn = Th < inf ? Tl + (Th - Tl) * 0.5f : T * 1.2f;
+        }
+        if (!(Tn > Tl) || !(Tn < Th)) break;
+        T = Tn;
+    }
+    if (c_ok == 0) { pbw_cursors_store<CAP>(L, W.ecur, lane); return -1; }
+    if (cnt != c_ok) pbw_cursors_store<CAP>(L, a_ok, lane);   // an overflow (or a dead end) after a usable shorter chunk: back to that one
+    pbw_cursors_load<CAP>(L, W.ecur, lane);                     // commit
+    tprev = lo; nprev = (float)done;
+    Tout = T_ok;
+    return c_ok;
+}
+
+// uniform search state of a frame (wave-uniform values)
+struct PbwState {
+    float best;
+    int j, nlive, cmp, suc1, suc2, bestidx;
+    u64 bestD, bestE;
+};
+
+// Sort-free pass over a chunk (the n keys as the walk left them, in no particular order).  The visit order matters to the
+// rules only through (i) "best so far", which changes only at a key whose cost beats the best the chunk STARTED with -- a
+// candidate; deep in a search a chunk holds none, or one or two -- and (ii) the frontier size, which matters only when it
+// can be 1.  So: every key's cost, frontier growth and rule 1 against the chunk-start best, in parallel and in any order;
+//   no candidate:  rule 1 depends on the sum alone, so the search stops at the SMALLEST firing sum, and the number of TEPs
+//                  visited is the number of smaller sums: one count, no sort;
+//   <= 16 candidates: they are put in visit order among themselves (a handful of comparisons), the records and their
+//                  success rule follow sequentially, rule 1 is re-evaluated for the keys behind the first record with the
+//                  best they see, and the stop / winner positions are counts again;
+//   otherwise -1 and nothing changed: the caller sorts the chunk (pbw_process_chunk).  That is: many candidates (the first
+//                  chunk or two), a frontier that may shrink to one entry (the first chunk, the tail of a complete scan),
+//                  or a key whose sum EQUALS that of a key a position is counted against (list order would decide; the
+//                  pass compares sums only, which keeps it small: it is compared against a handful of keys per chunk).
+// Returns 0 = no rule fired (state advanced), 1 = stopped (stop / ntep set), -1 = not handled.
+template <int CAP>
+__device__ __forceinline__ int pbw_scan_chunk(PbWaveLds<CAP> &L, const PbParams &P, const PbFrame &Fr, u64 d0, int n, float mn, float mx, int lane,
+                                              PbwState &S, int &stop, int &ntep)
+{
+    constexpr int PER = CAP / 64;
+    if (S.nlive <= 1) return -1;      // (the first chunk: one entry in the frontier, its pops are counted one by one)
+    float *const costs = reinterpret_cast<float *>(L.hist);
+    const float best0 = S.best;
+    // Rule 1 by probes.  With the best fixed, the rule's left-hand side bs = H[beta] + (A[beta] - H[beta]) w1 falls as the sum
+    // rises (w1 = exp(c4 rs) spl falls, beta -- a floor of a float quotient, monotone as computed -- falls, A >= H); the
+    // float32 evaluation follows that to a few units in the last place.  Lane l evaluates it at mn + (mx - mn)(l + 1) / 64:
+    // below the last probe that still clears the threshold by 0.1 % no key of the chunk can fire, and none is evaluated --
+    // every chunk of a search but its last.  Keys above it get the exact evaluation.
+    float r_safe;
+    {
+        const float rp = lane == 63 ? mx : mn + (mx - mn) * ((float)(lane + 1) * (1.0f / 64.0f));
+        float w1;
+        const float bs = pb_promising_bs(rp, best0, Fr, P.c4, L.cdfA, L.cdfH, w1);
+        const u64 unsafe = ~__ballot((double)bs > Fr.p_t_pro * 1.001);
+        const int u = unsafe ? __builtin_ctzll(unsafe) : 64;
+        r_safe = u == 0 ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rp), u - 1));
+    }
+    const auto parity = [&](const PbTep &t) {
+        u64 D = d0 ^ L.P[t.p0];
+        if (t.wt > 1) D ^= L.P[t.p1];
+        if (t.wt > 2) D ^= L.P[t.p2];
+        return D;
+    };
+    u64 kq[PER];
+    unsigned npneed = 0, npmask = 0;
+    int sumdel = 0, neg = 0, nsurv = 0;
+    unsigned short *const slist = reinterpret_cast<unsigned short *>(L.list);     // keys the cost bound could not rule out
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = lane + 64 * k;
+        kq[k] = ~0ull;
+        if (k * 64 < n) {
+            if (i < n) kq[k] = L.keys[i];
+            const PbTep t = pbw_tep((unsigned)kq[k]);
+            const float rs = __uint_as_float((unsigned)(kq[k] >> 32));      // (an empty slot: NaN, every test below is false)
+            const bool surv = i < n && pbw_cost_floor<CAP>(L, rs, parity(t)) < best0;
+            const u64 sm = __ballot(surv);
+            if (sm) {
+                if (surv) slist[nsurv + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] = (unsigned short)i;
+                nsurv += __popcll(sm);
+            }
+            npneed |= rs > r_safe ? 1u << k : 0u;
+            if (i < n) { const int dl = pb_delta(t, P.order); sumdel += dl; neg += dl < 0; }
+        }
+    }
+    const int negtot = wave_add_i32(neg), deltot = wave_add_i32(sumdel);
+    if (S.nlive - negtot <= 1) return -1;
+    // the survivors' costs, 64 at a time (the canonical summation, no LUT: ~200 instructions, but per BATCH); those that beat the
+    // chunk-start best are the candidates
+    int ncand = 0;
+    if (nsurv) {
+        wave_fence();
+        for (int b0 = 0; b0 < nsurv && ncand <= 16; b0 += 64) {
+            const bool has = b0 + lane < nsurv;
+            const u64 key = has ? L.keys[slist[b0 + lane]] : 0ull;
+            const float c = has ? pbw_cost_exact<CAP>(L, __uint_as_float((unsigned)(key >> 32)), parity(pbw_tep((unsigned)key))) : __builtin_inff();
+            const bool cand = c < best0;
+            const u64 cm = __ballot(cand);
+            if (cm) {
+                const int idx = ncand + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+                if (cand && idx < 16) { L.ck[idx] = key; L.cc[idx] = c; }
+                ncand += __popcll(cm);
+            }
+        }
+        if (ncand > 16) return -1;
+    }
+    // rule 1 for the keys above the last safe probe (the last chunk of a search; nothing elsewhere)
+    if (__ballot(npneed != 0)) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const bool need = (npneed >> k) & 1u;
+            if (__ballot(need)) {
+                float w1;
+                if (need && pb_not_promising(__uint_as_float((unsigned)(kq[k] >> 32)), best0, Fr, P.c4, L.cdfA, L.cdfH, w1)) npmask |= 1u << k;
+            }
+        }
+    }
+    // (sums are >= +0: their bit patterns order like the floats; an invalid slot holds all ones)
+    const auto sumbits = [](u64 key) { return (unsigned)(key >> 32); };
+    bool tie = false;
+    // number of my keys with a smaller sum than `ref`; a different key with the same sum is a tie
+    const auto count_before = [&](u64 ref) {
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            c += sumbits(kq[k]) < sumbits(ref);
+            tie |= sumbits(kq[k]) == sumbits(ref) && kq[k] != ref;
+        }
+        return wave_add_i32(c);
+    };
+    int nrec = 0, stop2 = 0;     // records among the candidates; stop2: the success rule fired on the last of them
+    if (ncand > 0) {
+        // ---- the candidates, in visit order
+        wave_fence();
+        {
+            const u64 my = L.ck[lane & 15];
+            const float myc = L.cc[lane & 15];
+            int r = 0;
+            for (int d = 0; d < ncand; ++d) { const u64 o = L.ck[d]; r += sumbits(o) < sumbits(my); tie |= lane < ncand && sumbits(o) == sumbits(my) && o != my; }
+            wave_fence();
+            if (lane < ncand) { L.ck[r] = my; L.cc[r] = myc; }
+            wave_fence();
+        }
+        if (__ballot(tie)) return -1;
+        // ---- records and the success rule, sequentially (every lane runs the same arithmetic on the same values)
+        float before = best0;
+        for (int t = 0; t < ncand && !stop2; ++t) {
+            const u64 key = L.ck[t];
+            const float c = L.cc[t];
+            if (c < before) {
+                if (lane == 0) { L.rk[nrec] = key; L.rc[nrec] = c; }
+                ++nrec;
+                const float w1 = det_expf(P.c4 * __uint_as_float((unsigned)(key >> 32))) * Fr.spl;
+                if (pb_success(parity(pbw_tep((unsigned)key)), w1, L.tq, Fr)) stop2 = 1;
+                before = c;
+            }
+        }
+        wave_fence();
+        // ---- rule 1 again for the keys behind the first record, with the best they see
+        if (nrec > 0) {
+            const unsigned s0 = sumbits(L.rk[0]);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                if (lane + 64 * k < n && sumbits(kq[k]) >= s0 && kq[k] != L.rk[0]) {
+                    int t = 0;
+                    for (int u = 0; u < nrec; ++u) { const u64 r = L.rk[u]; t += sumbits(r) < sumbits(kq[k]); tie |= sumbits(r) == sumbits(kq[k]) && r != kq[k]; }
+                    if (t > 0) {
+                        float w1;
+                        const bool np = pb_not_promising(__uint_as_float(sumbits(kq[k])), L.rc[t - 1], Fr, P.c4, L.cdfA, L.cdfH, w1);
+                        npmask = (npmask & ~(1u << k)) | (np ? 1u << k : 0u);
+                    }
+                }
+            }
+        }
+    }
+    // ---- the smallest sum on which rule 1 fires: every key of that sum sees the same best, so the first of them stops
+    unsigned fs = 0x7FFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (((npmask >> k) & 1u) && sumbits(kq[k]) < fs) fs = sumbits(kq[k]);
+    const unsigned sF = (unsigned)wave_min_i32((int)fs);
+    // ---- the stop: the earlier of rule 1's first key and the record on which rule 2 fired
+    int reason = 0;
+    unsigned sstop = 0;
+    if (sF != 0x7FFFFFFFu) { reason = 1; sstop = sF; }
+    if (stop2) {
+        const unsigned sR = sumbits(L.rk[nrec - 1]);
+        if (reason == 1 && sR == sF) tie = true;
+        if (reason == 0 || sR < sF) { reason = 2; sstop = sR; }
+    }
+    int nbefore = nrec;           // records that really happened: those before the stop (and the stop itself for rule 2)
+    if (reason) {
+        nbefore = 0;
+        for (int u = 0; u < nrec; ++u) nbefore += sumbits(L.rk[u]) < sstop;
+        nbefore += reason == 2;
+    }
+    int rank_best = 0, rank_stop = 0;
+    if (nbefore > 0) rank_best = count_before(L.rk[nbefore - 1]);
+    if (reason == 2) rank_stop = rank_best;
+    if (reason == 1) {   // (the keys of the stopping sum all fire: the first of them in list order is at this position, whichever it is)
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) c += sumbits(kq[k]) < sstop;
+        rank_stop = wave_add_i32(c);
+    }
+    if (__ballot(tie)) return -1;
+    // ---- commit
+    if (nbefore > 0) {
+        const u64 bk = L.rk[nbefore - 1];
+        const PbTep t = pbw_tep((unsigned)bk);
+        u64 E = 1ull << t.p0;
+        if (t.wt > 1) E |= 1ull << t.p1;
+        if (t.wt > 2) E |= 1ull << t.p2;
+        S.best = L.rc[nbefore - 1]; S.bestD = parity(t); S.bestE = E;
+        S.bestidx = S.j + rank_best + 1;
+    }
+    S.suc2 += nbefore;
+    if (reason) {
+        S.cmp += 2 * (rank_stop + 1);             // (the frontier never holds a single entry here: no one-comparison pops)
+        S.suc1 += reason == 1 ? rank_stop : rank_stop + 1;
+        stop = reason; ntep = S.j + rank_stop + 1;
+        return 1;
+    }
+    S.cmp += 2 * n; S.suc1 += n;
+    S.j += n; S.nlive += deltot;
+    return 0;
+}
+
+// The n keys of one chunk (all TEPs of a sum range (mn, mx]): sort into visit order, evaluate in parallel, apply the
+// sequential rules.  Returns 0 = no rule fired (state advanced), 1 = stopped (stop / ntep set), 2 = a run of more than
+// kPbMaxTie equal sums (frame goes to the list replay).
+template <int CAP, bool PROF>
+__device__ __forceinline__ int pbw_process_chunk(PbWaveLds<CAP> &L, const PbParams &P, const PbFrame &Fr, u64 d0, int n, float mn, float mx,
+                                                 int lane, PbwState &S, int &stop, int &ntep, unsigned long long (&pt)[kPwSlots], unsigned long long &plast)
+{
+    constexpr int PER = CAP / 64;
+    // ---- bucket sort: CAP buckets over (mn, mx], counts -> offsets -> scatter (grouped by bucket) -> every key counts the
+    // keys of its own bucket that sort before it.  Entries past a bucket's end belong to higher buckets (larger keys), past
+    // the chunk's end to the all-ones pad: the count needs no mask and runs to the wave's fullest bucket.
+    {
+        int4 *h4 = reinterpret_cast<int4 *>(&L.hist[lane * PER]);
+#pragma unroll
+        for (int k = 0; k < PER / 4; ++k) h4[k] = make_int4(0, 0, 0, 0);
+    }
+    const float scale = mx > mn ? (float)CAP / (mx - mn) : 0.0f;
+    const bool flat = !(scale < 3.0e38f);           // denormally close sums: one bucket
+    const auto bucket = [&](u64 key) {
+        const float sv = __uint_as_float((unsigned)(key >> 32));
+        return flat ? 0 : (int)__builtin_fminf((sv - mn) * scale, (float)(CAP - 1));
+    };
+    u64 kreg[PER];
+    int breg[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = lane + 64 * k;
+        kreg[k] = i < n ? L.keys[i] : ~0ull;
+        breg[k] = bucket(kreg[k]);
+    }
+    wave_fence();
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (lane + 64 * k < n) atomicAdd(&L.hist[breg[k]], 1);
+    wave_fence();
+    int maxsize;
+    {
+        int c[PER], local = 0, cmax = 0;
+        const int4 *h4 = reinterpret_cast<const int4 *>(&L.hist[lane * PER]);
+#pragma unroll
+        for (int k = 0; k < PER / 4; ++k) { const int4 v = h4[k]; c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w; }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { local += c[k]; cmax = c[k] > cmax ? c[k] : cmax; }
+        int run = wave_incl_add_dpp(local) - local;
+        maxsize = wave_max_i32(cmax);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const int t = c[k]; c[k] = run; run += t; }
+        int4 *o4 = reinterpret_cast<int4 *>(&L.hist[lane * PER]);
+#pragma unroll
+        for (int k = 0; k < PER / 4; ++k) o4[k] = make_int4(c[4 * k], c[4 * k + 1], c[4 * k + 2], c[4 * k + 3]);
+    }
+    wave_fence();
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (lane + 64 * k < n) L.keys[pbw_phys(atomicAdd(&L.hist[breg[k]], 1))] = kreg[k];     // every lane holds its keys: in place
+    L.keys[pbw_phys(n + lane)] = ~0ull;
+    wave_fence();   // hist[b] is now the END of bucket b
+    const int per = (n + 63) >> 6;
+    const int i0 = lane * per;
+    u64 kq[PER];
+    {
+        int st[PER], rk[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const bool valid = k < per && i0 + k < n;
+            kq[k] = valid ? L.keys[pbw_phys(i0 + k)] : ~0ull;
+            const int b = bucket(kq[k]);
+            st[k] = valid ? (b > 0 ? L.hist[b > 0 ? b - 1 : 0] : 0) : n;
+            rk[k] = 0;
+        }
+        if (maxsize <= 64) {
+            for (int t = 0; t < maxsize; ++t) {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) rk[k] += L.keys[pbw_phys(st[k] + t)] < kq[k];
+            }
+        } else {      // a crowded bucket (clustered sums): same count with the reads clamped to the pad
+            for (int t = 0; t < maxsize; ++t) {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) { const int x = st[k] + t; rk[k] += L.keys[pbw_phys(x < n ? x : n)] < kq[k]; }
+            }
+        }
+        wave_fence();
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (k < per && i0 + k < n) L.keys[pbw_phys(st[k] + rk[k])] = kq[k];
+        wave_fence();
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) kq[k] = (k < per && i0 + k < n) ? L.keys[pbw_phys(i0 + k)] : 0ull;
+    PBW_STAMP(kPwSort);
+    // ---- equal sums: list order (pb_visit_less).  A lane looks at its own entries (registers) and at the two entries next
+    // to them; the lane that owns the first entry of a run of equal sums puts the run in order.  (Not rare: a deep chunk
+    // spans ~2 % of a binade, 377 sums among ~170 k floats collide in one chunk out of three.)
+    {
+        const unsigned sprev = i0 > 0 && i0 < n ? (unsigned)(L.keys[pbw_phys(i0 - 1)] >> 32) : 0xFFFFFFFFu;
+        const unsigned snext = i0 + per < n ? (unsigned)(L.keys[pbw_phys(i0 + per)] >> 32) : 0xFFFFFFFFu;
+        unsigned starts = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = i0 + k;
+            if (k < per && i + 1 < n) {
+                const unsigned sk = (unsigned)(kq[k] >> 32);
+                const unsigned sn = (k + 1 < per) ? (unsigned)(kq[k + 1 < PER ? k + 1 : k] >> 32) : snext;
+                const unsigned sp = k > 0 ? (unsigned)(kq[k > 0 ? k - 1 : 0] >> 32) : sprev;
+                if (sn == sk && (i == 0 || sp != sk)) starts |= 1u << k;
+            }
+        }
+        if (__ballot(starts != 0)) {
+            bool degenerate = false;
+            for (unsigned m = starts; m; m &= m - 1) {
+                const int i = i0 + __builtin_ctz(m);
+                const unsigned si = (unsigned)(L.keys[pbw_phys(i)] >> 32);
+                int g = 2;
+                while (i + g < n && g <= kPbMaxTie && (unsigned)(L.keys[pbw_phys(i + g)] >> 32) == si) ++g;
+                if (g > kPbMaxTie) { degenerate = true; continue; }
+                for (int a = 1; a < g; ++a) {
+                    const u64 ka = L.keys[pbw_phys(i + a)];
+                    const PbTep ta = pbw_tep((unsigned)ka);
+                    int b = a;
+                    while (b > 0 && pb_visit_less(L.w, ta, pbw_tep((unsigned)L.keys[pbw_phys(i + b - 1)]))) { L.keys[pbw_phys(i + b)] = L.keys[pbw_phys(i + b - 1)]; --b; }
+                    L.keys[pbw_phys(i + b)] = ka;
+                }
+            }
+            if (__ballot(degenerate)) return 2;
+            wave_fence();
+#pragma unroll
+            for (int k = 0; k < PER; ++k) kq[k] = (k < per && i0 + k < n) ? L.keys[pbw_phys(i0 + k)] : 0ull;
+        }
+    }
+    PBW_STAMP(kPwTie);
+    // ---- evaluate: lane l owns the entries [l per, (l + 1) per) of the sorted chunk.  Rolled loops with the per-entry
+    // values in LDS (the costs go where the bucket counters were): as register arrays, fully unrolled, they and the 64 LUT
+    // reads the scheduler then hoists cost ~390 VGPRs -- one wavefront per SIMD.
+    float *const costs = reinterpret_cast<float *>(L.hist);
+    const auto parity = [&](const PbTep &t) {
+        u64 D = d0 ^ L.P[t.p0];
+        if (t.wt > 1) D ^= L.P[t.p1];
+        if (t.wt > 2) D ^= L.P[t.p2];
+        return D;
+    };
+    float tmin = __builtin_inff();
+    int tdel = 0;
+    // (rolled loops over the lane's entries, read back from LDS: this path only runs for the first chunk or two of a frame
+    //  -- pbw_scan_chunk takes the others -- and unrolled it is 8 k instructions of a kernel that should fit the I-cache)
+#pragma unroll 1
+    for (int k = 0; k < per; ++k) {
+        const int i = i0 + k;
+        if (i < n) {
+            const u64 key = L.keys[pbw_phys(i)];
+            const PbTep t = pbw_tep((unsigned)key);
+            const float c = pbw_cost<CAP>(L, __uint_as_float((unsigned)(key >> 32)), parity(t), S.best);   // (+inf if it cannot beat the best)
+            costs[i] = c;
+            tmin = __builtin_fminf(tmin, c);
+            tdel += pb_delta(t, P.order);
+        }
+    }
+    // exclusive scans over the lanes: min of the costs / sum of the frontier growth before my entries
+    const float imin = wave_incl_min_dpp(tmin);
+    const int iadd = wave_incl_add_dpp(tdel);
+    float before = __shfl_up(imin, 1, 64);
+    if (lane == 0) before = __builtin_inff();
+    before = __builtin_fminf(before, S.best);
+    int nlb = iadd - tdel + S.nlive;
+    const int tot_del = __builtin_amdgcn_readlane(iadd, 63);
+    PBW_STAMP(kPwEval);
+    // ---- the sequential rules on my entries, assuming no earlier stop (`before` is the running best)
+    int ones = 0, nev = 0, nnb = 0, lnb = -1, lstop = 0x7FFFFFFF, lreason = 0;
+    float lbest = 0.0f;
+    u64 lD = 0;
+    unsigned lcode = 0;
+#pragma unroll 1
+    for (int k = 0; k < per; ++k) {
+        const int i = i0 + k;
+        if (i < n && lstop == 0x7FFFFFFF) {
+            const u64 key = L.keys[pbw_phys(i)];
+            const float c = costs[i];
+            const PbTep t = pbw_tep((unsigned)key);
+            float w1;
+            const bool np = pb_not_promising(__uint_as_float((unsigned)(key >> 32)), before, Fr, P.c4, L.cdfA, L.cdfH, w1);
+            ones += nlb == 1;
+            nlb += pb_delta(t, P.order);
+            if (np) { lstop = i; lreason = 1; }
+            else {
+                ++nev;
+                if (c < before) {
+                    const u64 D = parity(t);
+                    before = c; lnb = i; ++nnb; lbest = c; lD = D; lcode = (unsigned)key;
+                    if (pb_success(D, w1, L.tq, Fr)) { lstop = i; lreason = 2; }
+                }
+            }
+        }
+    }
+    PBW_STAMP(kPwRules);
+    const int gstop = wave_min_i32(lstop);
+    {   // my entries count if they lie before (or contain) the first stop
+        const bool mine = i0 < n && i0 <= gstop;
+        const int o = wave_add_i32(mine ? ones : 0), e = wave_add_i32(mine ? nev : 0), b = wave_add_i32(mine ? nnb : 0);
+        const int l = wave_max_i32(mine ? lnb : -1);
+        const int npop = gstop != 0x7FFFFFFF ? gstop + 1 : n;
+        S.cmp += 2 * npop - o; S.suc1 += e; S.suc2 += b;
+        if (l >= 0) {   // the last improvement before the stop
+            const int src = __builtin_ctzll(__ballot(mine && lnb == l));
+            const unsigned code = (unsigned)__builtin_amdgcn_readlane((int)lcode, src);
+            const PbTep t = pbw_tep(code);
+            u64 E = 1ull << t.p0;
+            if (t.wt > 1) E |= 1ull << t.p1;
+            if (t.wt > 2) E |= 1ull << t.p2;
+            S.best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbest), src));
+            S.bestD = readlane64(lD, src);
+            S.bestE = E;
+            S.bestidx = S.j + l + 1;
+        }
+        if (gstop != 0x7FFFFFFF) {
+            const int src = __builtin_ctzll(__ballot(lstop == gstop));
+            stop = __builtin_amdgcn_readlane(lreason, src);
+            ntep = S.j + gstop + 1;
+            PBW_STAMP(kPwCombine);
+            return 1;
+        }
+    }
+    S.j += n; S.nlive += tot_del;
+    PBW_STAMP(kPwCombine);
+    return 0;
+}
+
+// search state handed from the chunk kernel to the latency-shaped kernel (sums <= lo are visited)
+struct PbCarry {
+    float lo, best;
+    int j, nlive, cmp, suc1, suc2, bestidx;
+    u64 bestD, bestE;
+};
+
+// One frame of list A per wavefront, from its first TEP to its stop (or to the end of the table); massive ties go to
+// list B (list replay).  Workgroup b serves sub-list b mod 16, entries b / 16, b / 16 + grid / 16, ...
+// (12 KiB of LDS per frame: 13 workgroups per CU; three wavefronts per SIMD asked of the register allocator)
+template <int CAP, bool PROF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb_wave_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                     const unsigned char *__restrict__ perm_in,
+                                                     const u64 *__restrict__ parity_in, PbParams P,
+                                                     const double *__restrict__ cdf_half, int *__restrict__ ctl,
+                                                     const int *__restrict__ listA, int *__restrict__ listB, int sub_cap,
+                                                     int *__restrict__ listC, PbCarry *__restrict__ carry,
+                                                     const PbPrep *__restrict__ prep, PbOut O, unsigned long long *__restrict__ prof_out)
+{
+    __shared__ PbWaveLds<CAP> L;
+    unsigned long long pt[kPwSlots] = {0}, plast = 0;
+    if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
+    const int lane = threadIdx.x;
+    const int sub = blockIdx.x & (kPbSub - 1);
+    const int len = ctl[kPbCtlLenA + kPbCtlLine * sub];
+    const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);      // TEPs of weight 1..order
+    bool have_cdfh = false;
+    for (int k = blockIdx.x >> 4; k < len; k += gridDim.x >> 4) {
+        if (!have_cdfh) {
+            L.cdfH[lane] = (float)cdf_half[lane];
+            if (lane == 0) L.cdfH[64] = (float)cdf_half[64];
+            have_cdfh = true;
+        }
+        const long long f = listA[sub * sub_cap + k];
+        const long long src = index ? index[f] : f;
+        if constexpr (PROF) { long long t = src; asm volatile("s_waitcnt vmcnt(0)" : "+v"(t)); PBW_STAMP(kPwLoad1); }
+        // ---- per-frame set-up (search_prepare): primed-order values, hard decisions, byte LUTs, order-0 discrepancy
+        const int o1 = perm_in[f * 128 + lane], o2 = perm_in[f * 128 + 64 + lane];
+        const u64 Prow = parity_in[f * 64 + lane];
+        const float y1 = y[src * 128 + o1], y2 = y[src * 128 + o2];
+        PbFrame Fr;
+        if (prep) {   // what pb_singles_kernel already computed for this frame
+            const PbPrep &R = prep[f];
+            const float qp = R.q[64 + lane];
+            L.tq[lane] = make_float2(2.0f * (1.0f - qp), 2.0f * qp);
+            L.cdfA[lane] = (float)R.cdfA[lane];
+            if (lane == 0) L.cdfA[64] = (float)R.cdfA[64];
+            Fr = R.fr;
+        }
+        L.w[lane] = __builtin_fabsf(y1);
+        L.w[lane + 64] = __builtin_fabsf(y2);
+        L.P[lane] = Prow;
+        const u64 hm = __ballot(!(y1 > 0.0f)), hp = __ballot(!(y2 > 0.0f));
+        wave_fence();
+        PBW_STAMP(kPwLoad2);
+        {   // pbw_cost_floor's table: every quarter's 16 parity weights in ascending order (rank sort inside the 16-lane row,
+            // ties by position; no assumption on the order the caller's front end left them in), their running sums
+            const float v = L.w[64 + lane];
+            const int g0 = lane & 48;
+            int r = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const float o = L.w[64 + g0 + u]; r += (o < v) || (o == v && g0 + u < lane); }
+            float *const srt = reinterpret_cast<float *>(L.keys);
+            srt[g0 + r] = v;
+            wave_fence();
+            float acc = srt[lane];
+            acc = acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111, 0xF, 0xF, true));   // row_shr:1,2,4,8:
+            acc = acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x112, 0xF, 0xF, true));   // running sums
+            acc = acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x114, 0xF, 0xF, true));   // inside a row
+            acc = acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x118, 0xF, 0xF, true));
+            L.tail[lane >> 4][(lane & 15) + 1] = acc * 0.99999f;
+            if ((lane & 15) == 0) L.tail[lane >> 4][0] = 0.0f;
+        }
+        const u64 d0 = wave_xor64(((hm >> lane) & 1) ? Prow : 0ull) ^ hp;
+        wave_fence();
+        PbwState S;
+        S.best = pbw_cost_exact<CAP>(L, 0.0f, d0);
+        S.j = 0; S.nlive = 1; S.cmp = 0; S.suc1 = 0; S.suc2 = 0; S.bestidx = 0; S.bestD = d0; S.bestE = 0;
+        if (!prep) {  // cross-check route (every frame from its first TEP): the frame quantities are computed here
+            float *q = reinterpret_cast<float *>(L.keys);
+            double *cdf64 = reinterpret_cast<double *>(L.keys) + 64;
+            Fr = pb_frame_setup(L.w, q, cdf64, P.c4, P.order, P.nmax, lane, S.best);
+            pb_success_terms(q, L.tq, lane);
+            L.cdfA[lane] = (float)cdf64[lane];
+            if (lane == 0) L.cdfA[64] = (float)cdf64[64];
+            wave_fence();
+        }
+        PbWalk W;
+        pbw_walk_init<CAP>(L, W, P.order, lane);
+        float lo = -1.0f;
+        int done = 0;
+        if (prep) {   // go on where pb_singles_kernel stopped: the nhead least reliable singles are visited (every other sum is larger)
+            const PbPrep &R = prep[f];
+            const int nh = R.nhead;
+            if (nh > 0) {
+                S.j = nh; S.nlive = nh; S.cmp = 2 * nh - (nh < 2 ? nh : 2); S.suc1 = nh; S.suc2 = R.hsuc2;
+                if (R.hsuc2 > 0) { S.best = R.hbest; S.bestidx = R.hbestidx; S.bestD = R.hbestD; S.bestE = R.hbestE; }
+                lo = L.w[64 - nh]; done = nh;
+                if (lane == 63) {   // the singles are item 31 of lane 63: cursor and next member
+                    W.ecur[7] = (W.ecur[7] & 0x00FFFFFFu) | ((unsigned)(64 - nh) << 24);
+                    W.nxt[31] = nh < 64 ? L.w[63 - nh] : pbw_nan();
+                }
+                L.cur[7][lane] = W.ecur[7];
+            }
+        }
+        PBW_STAMP(kPwSetup);
+        const float smax = P.order > 2 ? (L.w[0] + L.w[1]) + L.w[2] : (P.order > 1 ? L.w[0] + L.w[1] : L.w[0]);
+        int stop = 0, ntep = P.nmax, state = 0;   // state: 0 = searching, 1 = a rule fired, 2 = to the list replay, 3 = to the latency-shaped kernel
+        bool asked = false;
+        float tprev = 0.0f, nprev = 0.0f;
+        while (state == 0 && done < nall) {
+            float T;
+            int nwalks = 0;
+            const int n = pbw_next_chunk<CAP, PROF>(L, W, P.order, lo, done, nall, done == 0 ? P.t1 : P.t2, lane, T, tprev, nprev, nwalks, pt);
+            PBW_STAMP(kPwWalk);
+            if constexpr (PROF) { pt[kPwChunks] += 1; pt[kPwWalks] += nwalks; pt[kPwKeys] += n > 0 ? n : 0; }
+            if (n < 0) { state = 2; break; }
+            if (n == 0) break;
+            wave_fence();
+            const float cmn = lo < 0.0f ? L.w[63] : lo, cmx = T < __builtin_inff() ? T : smax;
+            state = pbw_scan_chunk<CAP>(L, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep);
+            PBW_STAMP(kPwScan);
+            if (state < 0) {
+                if constexpr (PROF) pt[kPwSorted] += 1;
+                state = pbw_process_chunk<CAP, PROF>(L, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep, pt, plast);
+            }
+            lo = T;
+            done += n;
+            if (state == 0 && done >= P.budget && !asked && done < nall) {
+                // a long search: the latency-shaped kernel takes it over if it still has room (at most kPbHeavyCap frames a call)
+                asked = true;
+                int slot = 0;
+                if (lane == 0) slot = atomicAdd(&ctl[kPbCtlLenC], 1);
+                slot = __builtin_amdgcn_readfirstlane(slot);
+                if (slot < kPbHeavyCap) {
+                    if (lane == 0) {
+                        PbCarry c;
+                        c.lo = lo; c.best = S.best; c.j = S.j; c.nlive = S.nlive; c.cmp = S.cmp; c.suc1 = S.suc1; c.suc2 = S.suc2;
+                        c.bestidx = S.bestidx; c.bestD = S.bestD; c.bestE = S.bestE;
+                        carry[slot] = c;
+                        listC[slot] = (int)f;
+                    }
+                    state = 3;
+                }
+            }
+        }
+        if (state == 3) { wave_fence(); continue; }
+        if (state == 2) {   // massive ties: the literal list replay decodes this frame
+            if (lane == 0) listB[atomicAdd(&ctl[kPbCtlLenB], 1)] = (int)f;
+            wave_fence();
+            continue;
+        }
+        {   // candidate (E = flipped MRB positions, D = parity discrepancy) -> codeword in ORIGINAL bit order
+            if (lane < 2) L.cw[lane] = 0;
+            wave_fence();
+            const u64 mrb_bits = hm ^ S.bestE, par_bits = S.bestD ^ hp;
+            if ((mrb_bits >> lane) & 1) atomicOr(&L.cw[o1 >> 6], 1ull << (o1 & 63));
+            if ((par_bits >> lane) & 1) atomicOr(&L.cw[o2 >> 6], 1ull << (o2 & 63));
+            wave_fence();
+            PBW_STAMP(kPwFinish);
+            if (lane < 2) O.cw[f * 2 + lane] = L.cw[lane];
+            if (lane == 0) {
+                if (O.metric) O.metric[f] = S.best;
+                if (O.best) O.best[f] = S.bestidx;
+                if (O.ntep) O.ntep[f] = ntep;
+                if (O.aux) { O.aux[f * 4] = S.cmp; O.aux[f * 4 + 1] = S.suc1; O.aux[f * 4 + 2] = S.suc2; O.aux[f * 4 + 3] = stop; }
+            }
+            wave_fence();
+        }
+        PBW_STAMP(kPwStore);
+        if constexpr (PROF) pt[kPwFrames] += 1;
+    }
+    if constexpr (PROF) { if (lane == 0 && pt[kPwFrames]) for (int k = 0; k < kPwSlots; ++k) atomicAdd(&prof_out[k], pt[k]); }
+}
+
+// ---------------------------------------------------------------------------------------
+// stage 2b: the LATENCY shape, for the few frames whose search runs long (round 2's stage-B kernel, kept for them).
+// One wavefront takes ~1 ms through a complete scan of 43 744 TEPs; at 2.5 dB one frame in 200 is such a scan and the
+// launch would last as long as they do.  A frame that has passed PbParams::budget TEPs in the chunk kernel is therefore
+// handed on -- with its search state, if fewer than kPbHeavyCap frames were before it -- to this kernel: 1024 threads
+// per frame, chunks of ~3072 TEPs generated by binary searches over 2080 items (PbItems), bucket sort, prefix scans
+// across 16 wavefronts: ~23 us per chunk, a complete scan in ~0.3 ms.  When MANY frames run long (1.0 dB) only the first
+// kPbHeavyCap leave; the others stay where throughput is better.
+// ---------------------------------------------------------------------------------------
+#define PB_STAMP(k) do { } while (0)
+enum { kProfSetup = 0, kProfPassA, kProfHist, kProfGather, kProfSort, kProfTie, kProfEval1, kProfEval2, kProfCombine, kProfFill,
+       kProfScatter, kProfFinish, kProfFrames, kProfChunks };
+__device__ __forceinline__ PbTep pb_tep(const uchar4 *__restrict__ tab, int id)
+{
+    const uchar4 t = tab[id];
+    return PbTep{t.x, t.y, t.z, t.w};
+}
 
 template <int NT, int CAP>
 struct __attribute__((aligned(16))) PbBlockLds {
@@ -444,11 +1444,6 @@ struct __attribute__((aligned(16))) PbBlockLds {
     unsigned long long prof[24], prof_last;   // diagnostic build only (LDPC_PB_PROFILE)
 };
 
-// In-kernel stamps of the diagnostic instantiation (PROF = true, launched only when LDPC_PB_PROFILE is set): thread 0
-// adds the shader cycles since the previous stamp to slot k.  The product instantiation contains none of this.
-enum { kProfSetup = 0, kProfPassA, kProfHist, kProfGather, kProfSort, kProfTie, kProfEval1, kProfEval2, kProfCombine, kProfFill,
-       kProfScatter, kProfFinish, kProfFrames, kProfChunks };
-#define PB_STAMP(k) do { if constexpr (PROF) { if (tid == 0) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); B.prof[k] += now__ - B.prof_last; B.prof_last = now__; } } } while (0)
 
 // ---------------------------------------------------------------------------------------
 // Direct enumeration of a sum range.  The positions are sorted by reliability (w[0] >= w[1] >= ...) and float addition is
@@ -604,20 +1599,6 @@ __device__ __forceinline__ void pb_items_write(PbBlockLds<NT, CAP> &B, PbItems<N
     }
 }
 
-// Typical bound of the N smallest sums in units of the smallest triple sum m3 = w61 + w62 + w63 (medians over decoding
-// failures at 2.5 dB; the ratio is scale-free and tight: +-6 % between the 10th and 90th percentile, where the count
-// changes like the ~6th power of the bound).  Only a first guess: pb_pick_bound corrects it with exact counts.
-__device__ __forceinline__ float pb_bound_guess(float n)
-{
-    const float l = __builtin_amdgcn_logf(n < 64.0f ? 64.0f : n);
-    const float x[8] = {8.0f, 9.0f, 10.0f, 11.0f, 12.0f, 13.0f, 14.2877f, 15.4168f};     // log2 of 256 ... 20000, 43744
-    const float g[8] = {0.80f, 0.89f, 1.02f, 1.14f, 1.23f, 1.33f, 1.52f, 2.2f};
-    if (l <= x[0]) return g[0] * __builtin_amdgcn_exp2f((l - x[0]) / 6.0f);
-    float r = g[7];
-#pragma unroll
-    for (int k = 6; k >= 0; --k) if (l <= x[k + 1]) r = g[k] + (g[k + 1] - g[k]) * (l - x[k]) / (x[k + 1] - x[k]);
-    return r;
-}
 
 // Upper bound T of the next chunk: 0 < #(lo < sum <= T) <= CAP, aimed at `target` members.  First guess from
 // pb_bound_guess (or, past the first chunk, from the growth exponent between the last two bounds), then corrected with the
@@ -866,13 +1847,6 @@ __device__ int pb_process_chunk(PbBlockLds<NT, CAP> &B, const uchar4 *__restrict
     return 0;
 }
 
-// search state handed from the stage-A kernel to the stage-B kernel
-struct PbCarry {
-    float lo, best;
-    int j, nlive, cmp, suc1, suc2, bestidx;
-    u64 bestD, bestE;
-};
-
 // per-frame set-up of the workgroup kernels: wavefront 0 prepares the frame, all wavefronts build the byte LUTs
 template <int NT, int CAP>
 __device__ __forceinline__ SearchFrame pb_block_setup(PbBlockLds<NT, CAP> &B, const float *__restrict__ y, long long src, long long f,
@@ -896,120 +1870,13 @@ __device__ __forceinline__ SearchFrame pb_block_setup(PbBlockLds<NT, CAP> &B, co
     for (int b = wave; b < 8; b += NT / 64) build_byte_luts<1>(L.lut + b, &L.w[64 + 8 * b], lane);
     if (wave == 0) {
         if (!prep) {
-            const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, P.c4, P.order, P.nmax, lane);
+            const PbFrame Fr = pb_frame_setup(L.w, B.q, B.cdfA, P.c4, P.order, P.nmax, lane);
             if (lane == 0) B.fr = Fr;
         }
         pb_success_terms(B.q, B.tq, lane);
     }
     __syncthreads();
     return S;
-}
-
-// Stage A of a frame of list A: the first two chunks of the visit order.  A frame on which no rule fires here goes on
-// to list C with its search state (pb_heavy_kernel), massive ties to list B (list replay).
-template <int NT, int CAP, bool PROF, int MINW = 1>
-__global__ __launch_bounds__(NT, MINW) void pb_block_kernel(const float *__restrict__ y, const int *__restrict__ index,
-                                                      const unsigned char *__restrict__ perm_in,
-                                                      const u64 *__restrict__ parity_in, PbParams P,
-                                                      const double *__restrict__ cdf_half,
-                                                      const uchar4 *__restrict__ tab, int *__restrict__ ctl,
-                                                      const int *__restrict__ listA, int *__restrict__ listB,
-                                                      int *__restrict__ listC, int sub_cap, PbCarry *__restrict__ carry,
-                                                      const PbPrep *__restrict__ prep, PbOut O,
-                                                      unsigned long long *__restrict__ prof_out)
-{
-    __shared__ PbBlockLds<NT, CAP> B;
-    SearchLds &L = B.s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // frames are drawn by ticket from the sub-lists of list A, starting with sub-list (workgroup mod 16) and moving on when
-    // one is exhausted; every sub-list has its own ticket word
-    if (tid < kPbSub) B.sublen[tid] = ctl[kPbCtlLenA + kPbCtlLine * tid];
-    if (tid == 0) { B.sub = blockIdx.x & (kPbSub - 1); B.subtried = 0; }
-    const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);
-    if (tid < 65) B.cdfH[tid] = cdf_half[tid];
-    PbItems<NT> I;
-    pb_items_static(I, tab, P.order, tid);
-    if constexpr (PROF) { if (tid < 24) B.prof[tid] = 0; if (tid == 0) B.prof_last = __builtin_amdgcn_s_memtime(); }
-
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) {
-            int tk = -1;
-            while (B.subtried < kPbSub) {
-                tk = atomicAdd(&ctl[kPbCtlTicketA + kPbCtlLine * B.sub], 1);
-                if (tk < B.sublen[B.sub]) break;
-                tk = -1; B.sub = (B.sub + 1) & (kPbSub - 1); ++B.subtried;
-            }
-            B.ticket = tk;
-        }
-        __syncthreads();
-        const int tk = B.ticket;
-        if (tk < 0) break;
-        const long long f = listA[B.sub * sub_cap + tk];
-        const long long src = index ? index[f] : f;
-        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, prep, tid);
-        if (tid == 0) {
-            B.lo = -1.0f; B.hi_cur = L.w[0];
-            B.j = 0; B.nlive = 1; B.cmp = 0; B.suc1 = 0; B.suc2 = 0; B.bestidx = 0;
-            B.bestD = B.d0; B.bestE = 0;
-            B.best = tep_cost(L, 0.0f, B.d0);
-        }
-        __syncthreads();
-        PB_STAMP(kProfSetup);
-        unsigned long long fstart = 0, fchunks = 0;
-        if constexpr (PROF) { fstart = __builtin_amdgcn_s_memtime(); fchunks = B.prof[kProfChunks]; }
-        const PbFrame Fr = B.fr;
-        const u64 d0 = B.d0;
-        int stop = 0, ntep = P.nmax, state = 0;   // state: 0 = searching, 1 = a rule fired, 2 = hand the frame to the list replay
-
-        // Two chunks of increasing sums here (aimed at ~512, then ~1536 TEPs: 88 % / 96 % of the frames that reach this
-        // kernel stop inside them); a frame that is still searching then goes to stage B with its state.
-        pb_items_frame(I, L.w, -1.0f);
-        const float smax = P.order > 2 ? (L.w[0] + L.w[1]) + L.w[2] : (P.order > 1 ? L.w[0] + L.w[1] : L.w[0]);
-        float lo = -1.0f;
-        int done = 0;
-        for (int chunk = 0; chunk < 2 && state == 0 && done < nall; ++chunk) {
-            int n, run;
-            const float T = pb_pick_bound(B, I, L.w, P.order, lo, done, nall, chunk == 0 ? P.t1 : P.t2, lane, wave, n, run);
-            PB_STAMP(kProfHist);
-            if (n < 0) { state = 2; break; }
-            pb_items_write(B, I, L.w, run);
-            __syncthreads();
-            PB_STAMP(kProfPassA);
-            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, lo < 0.0f ? L.w[63] : lo, T < __builtin_inff() ? T : smax, tid, stop, ntep);
-            lo = T;
-            done += n;
-        }
-        if (state == 0 && tid == 0) B.lo = lo;
-        __syncthreads();
-        if constexpr (PROF) {
-            if (tid == 0) {
-                const unsigned long long dt = __builtin_amdgcn_s_memtime() - fstart, dc = B.prof[kProfChunks] - fchunks;
-                B.prof[21] = dt > B.prof[21] ? dt : B.prof[21];
-                B.prof[22] = dc > B.prof[22] ? dc : B.prof[22];
-            }
-        }
-        if (state == 2) {   // massive ties: the literal list replay decodes this frame
-            if (tid == 0) listB[atomicAdd(&ctl[kPbCtlLenB], 1)] = (int)f;
-            continue;
-        }
-        if (state == 0 && done < nall) {   // no rule fired so far: the search goes on over the remaining TEPs
-            if (tid == 0) {
-                PbCarry c;
-                c.lo = B.lo; c.best = B.best; c.j = B.j; c.nlive = B.nlive; c.cmp = B.cmp; c.suc1 = B.suc1; c.suc2 = B.suc2;
-                c.bestidx = B.bestidx; c.bestD = B.bestD; c.bestE = B.bestE;
-                carry[f] = c;
-                const int sc = (int)f & (kPbSub - 1);
-                listC[sc * sub_cap + atomicAdd(&ctl[kPbCtlLenC + kPbCtlLine * sc], 1)] = (int)f;
-            }
-            continue;
-        }
-        if (wave == 0)
-            pb_write(L, S, O, f, lane, B.bestE, B.bestD, B.best, B.bestidx, ntep, B.cmp, B.suc1, B.suc2, stop);
-        if constexpr (PROF) { if (tid == 0) B.prof[kProfFrames] += 1; }
-        PB_STAMP(kProfFinish);
-    }
-    if constexpr (PROF) { __syncthreads(); if (tid < 21) atomicAdd(&prof_out[tid], B.prof[tid]); else if (tid < 24) atomicMax(&prof_out[tid], B.prof[tid]); }
 }
 
 // Stage B of a frame of list C: the visit order continues above the bound stage A reached, in chunks of up to 4096
@@ -1031,12 +1898,9 @@ __global__ __launch_bounds__(NT, MINW) void pb_heavy_kernel(const float *__restr
     PbBlockLds<NT, CAP> &B = *reinterpret_cast<PbBlockLds<NT, CAP> *>(pb_heavy_lds);
     SearchLds &L = B.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // tickets run over the concatenation of the 16 sub-lists of list C (a couple of thousand draws per call)
-    int cbase[kPbSub + 1];
-    cbase[0] = 0;
-#pragma unroll
-    for (int q = 0; q < kPbSub; ++q) cbase[q + 1] = cbase[q] + ctl[kPbCtlLenC + kPbCtlLine * q];
-    const int nlist = cbase[kPbSub];
+    // (list C holds at most kPbHeavyCap frames: one length word, one ticket word)
+    const int lenc = ctl[kPbCtlLenC];
+    const int nlist = lenc < kPbHeavyCap ? lenc : kPbHeavyCap;
     const int nall = P.order == 2 ? kPbTriples0 : kPbTabSize;
     if (tid < 65) B.cdfH[tid] = cdf_half[tid];
     PbItems<NT> I;
@@ -1049,17 +1913,11 @@ __global__ __launch_bounds__(NT, MINW) void pb_heavy_kernel(const float *__restr
         __syncthreads();
         const int tk = B.ticket;
         if (tk >= nlist) break;
-        int sc = 0;
-#pragma unroll
-        for (int q = 1; q < kPbSub; ++q) sc += tk >= cbase[q];
-        int cb = 0;
-#pragma unroll
-        for (int q = 0; q < kPbSub; ++q) cb = q == sc ? cbase[q] : cb;
-        const long long f = listC[sc * sub_cap + (tk - cb)];
+        const long long f = listC[tk];
         const long long src = index ? index[f] : f;
         const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, prep, tid);
         if (tid == 0) {
-            const PbCarry c = carry[f];
+            const PbCarry c = carry[tk];
             B.lo = c.lo; B.best = c.best; B.j = c.j; B.nlive = c.nlive; B.cmp = c.cmp; B.suc1 = c.suc1; B.suc2 = c.suc2;
             B.bestidx = c.bestidx; B.bestD = c.bestD; B.bestE = c.bestE;
         }
@@ -1130,7 +1988,7 @@ __global__ __launch_bounds__(256) void pb_seq_kernel(const float *__restrict__ y
         const long long f = listB[tk];
         const long long src = index ? index[f] : f;
         const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
-        const PbFrame Fr = pb_frame_setup(L, B.q, B.cdfA, P.c4, P.order, P.nmax, lane);
+        const PbFrame Fr = pb_frame_setup(L.w, B.q, B.cdfA, P.c4, P.order, P.nmax, lane);
         const float spl = Fr.spl, lrb_mean = Fr.lrb_mean;
         const double p_t_suc = Fr.p_t_suc, p_t_pro = Fr.p_t_pro;
         if (lane == 0) {   // starting point: the single TEP {k-1} (pb_testing.py:109-110)
@@ -1289,13 +2147,11 @@ __global__ __launch_bounds__(64) void pb_ctl_clear_kernel(int *__restrict__ ctl)
 
 int pb_ctx_init(ldpc_ctx *ctx)
 {
+    // (the chunk kernel generates its TEPs from the sorted reliabilities; the latency-shaped kernel reads this table: ids
+    //  0..63 = {63 - id}, 64..2079 the pairs, 2080..43743 the triples, each class by DESCENDING smallest position)
     OsdState *st = state(ctx);
     LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_heavy_kernel<1024, 4096, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(PbBlockLds<1024, 4096>)));
-    LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_heavy_kernel<1024, 4096, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)sizeof(PbBlockLds<1024, 4096>)));
-    LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_heavy_kernel<512, 2048, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)sizeof(PbBlockLds<512, 2048>)));
     std::vector<uchar4> tab;
     tab.reserve(kPbTabSize);
     for (int p = 63; p >= 0; --p) tab.push_back(make_uchar4((unsigned char)p, 0, 0, 1));
@@ -1310,6 +2166,17 @@ int pb_ctx_init(ldpc_ctx *ctx)
     return LDPC_OK;
 }
 
+// list replay: the list is append-only, at most 1 + 2 (N_max - 1) slots; spilled slots first, spilled chunk minima after
+static int pb_spill_layout(ldpc_ctx *ctx, int order, int64_t *spill_slots, int64_t *stride)
+{
+    const int64_t nmax = state(ctx)->ntep[order];
+    const int64_t slots = 2 * nmax + 2;
+    if (slots > (int64_t)kPbSuper * 4096) return fail(LDPC_E_UNSUPPORTED, "ldpc_osd_decode: PB-OSD list of %lld slots exceeds the kernel's limit", (long long)slots);
+    *spill_slots = slots > kPbLdsSlots ? slots - kPbLdsSlots : 0;
+    *stride = *spill_slots + (slots / 64 + 2) + 2;
+    return LDPC_OK;
+}
+
 // PB-OSD part of a stream's workspace: control words, the two frame lists, the list replay's spill areas
 static int stream_ws_pb(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int64_t spill_stride, StreamWs **out)
 {
@@ -1317,17 +2184,23 @@ static int stream_ws_pb(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int64_t sp
     std::lock_guard<std::mutex> lock(st->mu);
     StreamWs &w = st->ws[s];
     const bool grow_list = frames > w.pb_cap || !w.d_pb_ctl, grow_spill = spill_stride > w.pb_spill_stride;
-    if ((grow_list || grow_spill) && stream_capturing(s))
-        return fail(LDPC_E_NOMEM, "PB-OSD workspace of this stream must be sized before capturing (run one call on the stream first)");
+    const bool capturing = stream_capturing(s);
+    if ((grow_list || grow_spill) && capturing)
+        return fail(LDPC_E_NOMEM, "PB-OSD workspace of this stream must be sized before capturing (ldpc_osd_reserve_stream with the "
+                    "PB-OSD parameters, or one eager call on the stream)");
+    if ((grow_list || grow_spill) && w.captured)
+        return fail(LDPC_E_NOMEM, "PB-OSD workspace of this stream is referenced by a captured graph and cannot grow: destroy the graph and "
+                    "call ldpc_osd_release_stream, or reserve the larger size before capturing");
+    if (capturing) w.captured = true;
     if (grow_list) {
         (void)hipFree(w.d_pb_list); w.d_pb_list = nullptr; w.pb_cap = 0;
         if (!w.d_pb_ctl && hipMalloc((void **)&w.d_pb_ctl, sizeof(int) * kPbCtlInts) != hipSuccess)
             return fail(LDPC_E_NOMEM, "PB-OSD control words could not be allocated");
-        (void)hipFree(w.d_pb_carry); w.d_pb_carry = nullptr;
         (void)hipFree(w.d_pb_prep); w.d_pb_prep = nullptr;
+        (void)hipFree(w.d_pb_carry); w.d_pb_carry = nullptr;
         const int64_t sub_cap = (frames + kPbSub - 1) / kPbSub;
-        if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * 3 * (size_t)kPbSub * (size_t)sub_cap) != hipSuccess ||
-            hipMalloc(&w.d_pb_carry, sizeof(PbCarry) * (size_t)frames) != hipSuccess ||
+        if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * (2 * (size_t)kPbSub * (size_t)sub_cap + kPbHeavyCap)) != hipSuccess ||
+            hipMalloc(&w.d_pb_carry, sizeof(PbCarry) * kPbHeavyCap) != hipSuccess ||
             hipMalloc(&w.d_pb_prep, sizeof(PbPrep) * (size_t)frames) != hipSuccess)
             return fail(LDPC_E_NOMEM, "PB-OSD frame lists for %lld frames could not be allocated", (long long)frames);
         w.pb_cap = frames; w.pb_sub_cap = sub_cap;
@@ -1342,28 +2215,37 @@ static int stream_ws_pb(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int64_t sp
     return LDPC_OK;
 }
 
+// ldpc_osd_reserve_stream for algo = PB: everything launch_pb would allocate for `frames` frames of this order
+int pb_reserve(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int order)
+{
+    int64_t spill_slots, stride;
+    if (int rc = pb_spill_layout(ctx, order, &spill_slots, &stride)) return rc;
+    StreamWs *w;
+    return stream_ws_pb(ctx, s, frames, stride, &w);
+}
+
 int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
               const unsigned char *d_perm, const u64 *d_parity, const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric,
               int32_t *d_best, int32_t *d_ntep, hipStream_t s)
 {
     OsdState *st = state(ctx);
     const int64_t nmax = st->ntep[p->order];
-    // list replay: the list is append-only, at most 1 + 2 (N_max - 1) slots; spilled slots first, spilled chunk minima after
-    const int64_t slots = 2 * nmax + 2;
-    if (slots > (int64_t)kPbSuper * 4096) return fail(LDPC_E_UNSUPPORTED, "ldpc_osd_decode: PB-OSD list of %lld slots exceeds the kernel's limit", (long long)slots);
-    const int64_t spill_slots = slots > kPbLdsSlots ? slots - kPbLdsSlots : 0;
-    const int64_t stride = spill_slots + (slots / 64 + 2) + 2;
-    StreamWs *w;
-    int rc = stream_ws_pb(ctx, s, F, stride, &w);
+    int64_t spill_slots, stride;
+    int rc = pb_spill_layout(ctx, p->order, &spill_slots, &stride);
     if (rc) return rc;
+    StreamWs *w;
+    if ((rc = stream_ws_pb(ctx, s, F, stride, &w))) return rc;
     PbParams pp;
     pp.order = p->order; pp.nmax = (int)nmax; pp.cmin_off = spill_slots;
-    pp.t1 = 768; pp.t2 = 768; pp.t3 = 3072;   // 3/4 of the chunk capacities (measured flat between 512 and 1536 for stage A)
+    pp.t3 = 3072; pp.budget = 4096;
+    if (const char *e = getenv("LDPC_PB_BUDGET")) pp.budget = atoi(e);   // (tuning aid)
+    pp.t1 = 320; pp.t2 = kPbWaveCap * 13 / 16;   // chunk targets: the first chunk's count is only guessed (+-40 %), the others follow the growth of the counts
     pp.c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)p->snr_db / 10.0)));    // -4 * noise_variance, pb_testing.py:50-52
     const int mode = (p->reserved & 4) ? 2 : ((p->reserved & 2) ? 1 : 0);
     PbOut O{reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep, reinterpret_cast<int *>(p->d_aux)};
     const int64_t list_len = (int64_t)kPbSub * w->pb_sub_cap;   // >= pb_cap
     int *listA = w->d_pb_list, *listB = w->d_pb_list + list_len, *listC = w->d_pb_list + 2 * list_len;
+    PbCarry *carry = reinterpret_cast<PbCarry *>(w->d_pb_carry);
     const int sub_cap = (int)w->pb_sub_cap;
     PbPrep *prep_w = reinterpret_cast<PbPrep *>(w->d_pb_prep);
     hipLaunchKernelGGL(pb_ctl_clear_kernel, dim3(1), dim3(64), 0, s, w->d_pb_ctl);
@@ -1385,47 +2267,32 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
         fprintf(stderr, "[LDPC_PB_PROFILE] singles kernel, cycles of lane 0 summed over wavefronts: start+perm/P' loads=%llu y loads+LUT=%llu frame_setup=%llu rules=%llu hand_on=%llu write=%llu\n",
                 h[5], h[0], h[1], h[2], h[3], h[4]);
     }
-    // stage A: a multiple of 16 workgroups (one sixteenth of them per sub-list), at most the 1024 that are resident
-    const unsigned g2 = (unsigned)(F < 1024 ? ((F + kPbSub - 1) / kPbSub) * kPbSub : 1024), g2b = (unsigned)(F < kPbHeavyGrid ? F : kPbHeavyGrid);
-    PbCarry *carry = reinterpret_cast<PbCarry *>(w->d_pb_carry);
+    // chunk kernel: one workgroup (= one wavefront) per (sub-list, entry); a multiple of 16 workgroups, at most 65 536 (a
+    // workgroup then takes every 4096th entry of its sub-list).  Workgroups beyond their sub-list's length leave at once.
+    const int64_t g2w = ((F + kPbSub - 1) / kPbSub) * kPbSub;
+    const unsigned g2 = (unsigned)(g2w < 65536 ? g2w : 65536);
     const PbPrep *prep = mode == 0 ? prep_w : nullptr;    // (cross-check routes skip the stage that fills it)
-    static const bool profile = getenv("LDPC_PB_PROFILE") != nullptr;   // diagnostic build of the two workgroup kernels
-    if (!profile) {
-        hipLaunchKernelGGL((pb_block_kernel<256, 1024, false, 4>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, sub_cap, carry, prep, O, (unsigned long long *)nullptr);
-        // Two shapes of the stage-B kernel.  Few, long searches (the usual case from ~2.25 dB up): the launch lasts as long
-        // as its longest frames, and one 1024-thread workgroup per CU with 4096-TEP chunks gets a frame through fastest.
-        // Many searches (low SNR: at 1.0 dB 83 % of the frames reach the OSD and most of them this stage): throughput counts,
-        // and two 512-thread workgroups per CU with 2048-TEP chunks interleave their barrier-separated phases -- +29 % at
-        // 1.0 dB, +21 % at 1.5 dB, -9 % at 3.0 dB.  The SNR the caller decodes for tells the two regimes apart.
-        if (p->snr_db < 2.25f) {
-            pp.t3 = 1792;
-            hipLaunchKernelGGL((pb_heavy_kernel<512, 2048, false, 4>), dim3(g2b), dim3(512), sizeof(PbBlockLds<512, 2048>), s, d_y, d_index, d_perm,
-                               d_parity, pp, st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, sub_cap, carry, prep, O, (unsigned long long *)nullptr);
-        } else {
-            hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, false>), dim3(g2b), dim3(1024), sizeof(PbBlockLds<1024, 4096>), s, d_y, d_index, d_perm,
-                               d_parity, pp, st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, sub_cap, carry, prep, O, (unsigned long long *)nullptr);
-        }
+    if (!profile_s) {
+        hipLaunchKernelGGL((pb_wave_kernel<kPbWaveCap, false>), dim3(g2), dim3(64), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half, w->d_pb_ctl,
+                           listA, listB, sub_cap, listC, carry, prep, O, (unsigned long long *)nullptr);
     } else {
-        static unsigned long long *d_prof = nullptr;
-        if (!d_prof) LDPC_HIP(hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 48));
-        LDPC_HIP(hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 48, s));
-        hipLaunchKernelGGL((pb_block_kernel<256, 1024, true, 4>), dim3(g2), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listA, listB, listC, sub_cap, carry, prep, O, d_prof);
-        hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, true>), dim3(g2b), dim3(1024), sizeof(PbBlockLds<1024, 4096>), s, d_y, d_index, d_perm, d_parity, pp,
-                           st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, sub_cap, carry, prep, O, d_prof + 24);
-        unsigned long long h[48];
-        LDPC_HIP(hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, s));
+        static unsigned long long *d_pw = nullptr;
+        if (!d_pw) LDPC_HIP(hipMalloc((void **)&d_pw, sizeof(unsigned long long) * kPwSlots));
+        LDPC_HIP(hipMemsetAsync(d_pw, 0, sizeof(unsigned long long) * kPwSlots, s));
+        hipLaunchKernelGGL((pb_wave_kernel<kPbWaveCap, true>), dim3(g2), dim3(64), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half, w->d_pb_ctl,
+                           listA, listB, sub_cap, listC, carry, prep, O, d_pw);
+        unsigned long long h[kPwSlots];
+        LDPC_HIP(hipMemcpyAsync(h, d_pw, sizeof(h), hipMemcpyDeviceToHost, s));
         LDPC_HIP(hipStreamSynchronize(s));
-        static const char *names[24] = {"setup", "write(A)", "bound", "write(B)", "sort", "tie", "eval1", "eval2", "combine", "items", "scatter",
-                                        "finish", "FRAMES", "CHUNKS", "FALLBACKS", "KEYS", "s.minmax", "s.count", "s.scan", "s.scatter",
-                                        "s.fix", "MAXFRAMECYC", "MAXFRAMECHUNKS", "-"};
-        for (int k = 0; k < 2; ++k) {
-            fprintf(stderr, "[LDPC_PB_PROFILE] %s kernel, cycles of thread 0 summed over workgroups:", k ? "stage-B" : "stage-A");
-            for (int q = 0; q < 23; ++q) fprintf(stderr, " %s=%llu", names[q], h[24 * k + q]);
-            fprintf(stderr, "\n");
-        }
+        static const char *names[kPwSlots] = {"setup", "walk", "sort", "tie", "eval", "rules", "combine", "finish", "FRAMES", "CHUNKS", "WALKS", "KEYS", "sweepA", "sweepB", "dense", "ROUNDS", "TRIPS", "scan", "SORTEDCHUNKS", "load1", "load2", "store"};
+        fprintf(stderr, "[LDPC_PB_PROFILE] chunk kernel, shader-clock ticks summed over wavefronts:");
+        for (int q = 0; q < kPwSlots; ++q) fprintf(stderr, " %s=%llu", names[q], h[q]);
+        fprintf(stderr, "\n");
     }
+    // the long searches the chunk kernel handed on (at most kPbHeavyCap; the workgroups find an empty list otherwise)
+    hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, false>), dim3((unsigned)(F < kPbHeavyCap ? F : kPbHeavyCap)), dim3(1024), sizeof(PbBlockLds<1024, 4096>), s,
+                       d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, sub_cap, carry, prep, O,
+                       (unsigned long long *)nullptr);
     const unsigned g3 = (unsigned)(want < kPbSeqBlocks ? (want < 1 ? 1 : want) : kPbSeqBlocks);
     hipLaunchKernelGGL(pb_seq_kernel, dim3(g3), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half,
                        reinterpret_cast<PbEntry *>(w->d_pb_spill), (long long)w->pb_spill_stride, w->d_pb_ctl, listB, O);

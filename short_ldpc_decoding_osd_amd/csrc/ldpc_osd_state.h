@@ -12,26 +12,27 @@ struct StreamWs {
     unsigned char *d_perm = nullptr;  // ldpc_osd_decode: front-end results [cap][128]
     u64 *d_parity = nullptr;          //                                    [cap][64]
     int64_t cap = 0;
+    int *d_index_safe = nullptr;      // ldpc_osd_params.y_frames: the sanitised copy of the caller's frame list [index_cap]
+    int64_t index_cap = 0;
     int *d_pb_ctl = nullptr;          // PB-OSD: list lengths and tickets (kPbCtlInts ints, zeroed per call)
-    int *d_pb_list = nullptr;         // PB-OSD: [3][kPbSub * pb_sub_cap] frames handed on: list A (stage A), B (list replay), C (stage B)
-    void *d_pb_carry = nullptr;       // PB-OSD: [pb_cap] search state of the frames on list C
+    int *d_pb_list = nullptr;         // PB-OSD: [2][kPbSub * pb_sub_cap] frames handed on: list A (chunk kernel), B (list replay); then list C [kPbHeavyCap]
+    void *d_pb_carry = nullptr;       // PB-OSD: [kPbHeavyCap] search state of the frames on list C (latency-shaped kernel)
     void *d_pb_prep = nullptr;        // PB-OSD: [pb_cap] per-frame probabilities / CDF table of the frames handed on (1 KiB each)
     int64_t pb_cap = 0, pb_sub_cap = 0;
     void *d_pb_spill = nullptr;       // PB-OSD sequential kernel: frontier overflow [waves][stride]
     int64_t pb_spill_stride = 0;
+    bool captured = false;            // a hipGraph was captured on this stream: its nodes hold these pointers, so the
+                                      // buffers can no longer be moved (growth is refused until ldpc_osd_release_stream)
 };
 // A device-scope atomic on ONE word saturates at ~88 returning fetch-adds per us (MI355X_MICROARCH.md): 11 k frames
-// appended to one list through one counter kept the first PB stage at 150 us whatever else it did.  Lists A and C are
-// therefore 16 sub-lists (frame f -> sub-list f mod 16), every length on its own 128-byte line; stage A walks its
-// sub-list through that sub-list's own ticket counter and moves on to the next one when it is exhausted (a static
-// stride over the sub-list was measured: 432 instead of 398 us, the frames' run times differ too much), stage B draws
-// tickets over the concatenation of the 16.
+// appended to one list through one counter kept the first PB stage at 150 us whatever else it did.  List A is
+// therefore 16 sub-lists (frame f -> sub-list f mod 16), every length on its own 128-byte line; workgroup b of the
+// chunk kernel serves entry b / 16 of sub-list b mod 16 (no tickets).
 constexpr int kPbSub = 16, kPbCtlLine = 32;
-constexpr int kPbCtlLenA = 0, kPbCtlLenC = kPbSub * kPbCtlLine, kPbCtlLenB = 2 * kPbSub * kPbCtlLine,
-              kPbCtlTicketB = kPbCtlLenB + kPbCtlLine, kPbCtlTicketC = kPbCtlLenB + 2 * kPbCtlLine;
-constexpr int kPbCtlTicketA = kPbCtlTicketC + kPbCtlLine;   // 16 lines
-constexpr int kPbCtlInts = kPbCtlTicketA + kPbSub * kPbCtlLine;
-constexpr int kPbHeavyGrid = 512;     // grid of the stage-B PB kernel (frames are drawn by ticket)
+constexpr int kPbCtlLenA = 0, kPbCtlLenB = kPbSub * kPbCtlLine, kPbCtlTicketB = kPbCtlLenB + kPbCtlLine;
+constexpr int kPbCtlLenC = kPbCtlTicketB + kPbCtlLine, kPbCtlTicketC = kPbCtlLenC + kPbCtlLine;
+constexpr int kPbCtlInts = kPbCtlTicketC + kPbCtlLine;
+constexpr int kPbHeavyCap = 1024;     // long searches a call may hand to the latency-shaped kernel (four per CU)
 constexpr int kPbSeqBlocks = 64;      // grid of the sequential PB kernel (each of its 4 x 64 waves owns a spill area)
 
 struct OsdState {
@@ -39,7 +40,8 @@ struct OsdState {
     uchar4 *d_tep_fs = nullptr;       // FS visit order, weight classes 1..3 back to back
     int *d_base2 = nullptr;           // order-2 ranks: number of index pairs with a larger sum
     double *d_cdf_half = nullptr;     // PB-OSD: P[Bin(64, 1/2) <= b], b = 0..64
-    uchar4 *d_pb_tab = nullptr;       // PB-OSD: TEPs by weight class, each class by descending smallest position (pb_tables)
+    uchar4 *d_pb_tab = nullptr;       // PB-OSD, latency-shaped kernel: TEPs by weight class, each class by descending smallest position
+    unsigned long long *d_index_errors = nullptr;   // ldpc_osd_params.y_frames: out-of-range entries met so far
     int fs_off[4] = {0, 0, 0, 0}, fs_cnt[4] = {0, 0, 0, 0};
     std::mutex mu;                    // guards `ws` and `reserve_frames`
     std::unordered_map<hipStream_t, StreamWs> ws;
@@ -53,6 +55,7 @@ int pb_ctx_init(ldpc_ctx *ctx);
 int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
               const unsigned char *d_perm, const u64 *d_parity, const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric,
               int32_t *d_best, int32_t *d_ntep, hipStream_t s);
+int pb_reserve(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int order);
 // ldpc_osd.hip
 bool stream_capturing(hipStream_t s);
 

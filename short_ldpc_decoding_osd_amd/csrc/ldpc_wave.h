@@ -104,6 +104,18 @@ __device__ __forceinline__ int wave_incl_add_dpp(int x)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
     return v;
 }
+// the same for floats (the additions run in the ladder's order, not ascending: for bounds and statistics only)
+__device__ __forceinline__ float wave_incl_addf_dpp(float x)
+{
+    float v = x;
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+    return v;
+}
 // inclusive prefix minimum over the lanes, same DPP ladder (a lane without a source keeps its own value)
 __device__ __forceinline__ float wave_incl_min_dpp(float x)
 {
@@ -265,10 +277,11 @@ __device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1,
 // out in descending order, and every key counts the keys of ITS OWN bucket that sort before it: ~4 mates (a dozen
 // in the fullest bucket) instead of all 128 -- the all-pairs form spent 512 vector instructions on 256 compare +
 // add-carry pairs per lane.  Entries past a bucket's end belong to lower buckets, i.e. smaller keys, so the count
-// may run on to the wave's largest bucket size without a mask; 64 zero entries pad the array.
+// may run on to the wave's largest bucket size without a mask; 128 zero entries pad the array (a bucket may start at
+// 127 and the wave's fullest bucket may hold all 128 keys -- clipped or saturated inputs -- so reads reach entry 254).
 // ---------------------------------------------------------------------------------------
 struct __attribute__((aligned(16))) RankLds {
-    u64 bk[192];             // the keys grouped by bucket (descending), then 64 zero entries (never "before me")
+    u64 bk[256];             // the keys grouped by bucket (descending), then 128 zero entries (never "before me")
     int hist[64], cur[64];   // bucket counts / placement cursors
     int base[64];            // number of keys in higher buckets
 };
@@ -284,7 +297,7 @@ __device__ __forceinline__ int bucket_of(unsigned a, float scale) { return (int)
 
 __device__ __forceinline__ void bucket_ranks(RankLds &R, u64 k1, u64 k2, int b1, int b2, int lane, int &r1, int &r2)
 {
-    R.hist[lane] = 0; R.cur[lane] = 0; R.bk[128 + lane] = 0ull;
+    R.hist[lane] = 0; R.cur[lane] = 0; R.bk[128 + lane] = 0ull; R.bk[192 + lane] = 0ull;
     wave_fence();
     atomicAdd(&R.hist[b1], 1); atomicAdd(&R.hist[b2], 1);
     wave_fence();

@@ -134,9 +134,23 @@ class Decoder:
         """Pre-size the OSD workspace (needed before capturing decode calls into a graph)."""
         _lib.check(self.L.ldpc_osd_reserve(self._ctx, int(max_frames)), "ldpc_osd_reserve")
 
-    def osd_reserve_stream(self, max_frames):
-        """Pre-size the OSD workspace of the CURRENT stream (instead of one eager call on it before a capture)."""
-        _lib.check(self.L.ldpc_osd_reserve_stream(self._ctx, int(max_frames), self._stream()), "ldpc_osd_reserve_stream")
+    def osd_reserve_stream(self, max_frames, params=None):
+        """Pre-size the OSD workspace of the CURRENT stream (instead of one eager call on it before a capture).
+        ``params`` (osd_params(...)): also size what that search needs (PB-OSD lists and tables)."""
+        _lib.check(self.L.ldpc_osd_reserve_stream(self._ctx, int(max_frames), C.byref(params) if params is not None else None,
+                                                  self._stream()), "ldpc_osd_reserve_stream")
+
+    def osd_release_stream(self, stream=None):
+        """Free the OSD workspace of ``stream`` (default: the current stream).  The stream must be idle and graphs
+        captured on it must not be replayed afterwards (include/ldpc_osd.h, 'Captured graphs')."""
+        st = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        _lib.check(self.L.ldpc_osd_release_stream(self._ctx, st), "ldpc_osd_release_stream")
+
+    def osd_index_errors(self):
+        """Out-of-range frame-list entries met by calls that carried ``y_frames`` (synchronises the device)."""
+        n = C.c_int64(0)
+        _lib.check(self.L.ldpc_osd_index_errors(self._ctx, C.byref(n)), "ldpc_osd_index_errors")
+        return int(n.value)
 
     def osd_ge(self, rows):
         """Device GF(2) elimination of [F,64,2] packed matrices -> (reduced, swaps[F,64,2] u8, nswaps[F])."""
@@ -165,17 +179,19 @@ class Decoder:
         return perm, parity, ns
 
     def osd_params(self, order, algo=_lib.OSD_CONVENTIONAL, snr_db=0.0, fs_beta=0.1, fs_tau_e=6.5, fs_tau_psc=30.0,
-                   fs_reference_quirk=1, aux=None, table_scan=False, pb_path=None, readlane_scan=False):
+                   fs_reference_quirk=1, aux=None, table_scan=False, pb_path=None, readlane_scan=False, y_frames=0):
         """aux: optional int32 tensor [F,4] receiving the PB-OSD per-frame statistics;
         table_scan: use the table-driven conventional kernel also for order 2 (cross-check path);
-        pb_path: None = staged PB-OSD kernels, "block" = every frame through the sorted-chunk workgroup
-        kernel, "replay" = every frame through the literal list replay (cross-check paths);
+        pb_path: None = staged PB-OSD kernels, "block" = every frame through the sorted-chunk kernel from its
+        first TEP, "replay" = every frame through the literal list replay (cross-check paths);
         readlane_scan: conventional order 2 through the first register-resident kernel (triangular pairing by
-        v_readlane) instead of the rotation-paired persistent one (cross-check path)."""
+        v_readlane) instead of the rotation-paired persistent one (cross-check path);
+        y_frames: debug bound for caller-made frame lists (0 = off): entries of ``index`` outside [0, y_frames) are
+        replaced by 0 and counted (``osd_index_errors``)."""
         flags = (1 if table_scan else 0) | {None: 0, "block": 2, "replay": 4}[pb_path] | (8 if readlane_scan else 0)
         return _lib.OsdParams(int(order), int(algo), float(snr_db), float(fs_beta), float(fs_tau_e),
                               float(fs_tau_psc), int(fs_reference_quirk), flags,
-                              aux.data_ptr() if aux is not None else None)
+                              aux.data_ptr() if aux is not None else None, int(y_frames))
 
     def osd_decode(self, y, order, algo=_lib.OSD_CONVENTIONAL, index=None, count=None, F=None, params=None, out=None):
         """OSD of the frames y[index[f]] (or y[f]).  Returns dict(cw[F,2] int64 original bit

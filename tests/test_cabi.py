@@ -18,7 +18,10 @@ def test_header_and_binding_agree():
     L = _lib.load()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.ldpc_abi_version() == 2
+    assert L.ldpc_abi_version() == int(re.search(r"#define LDPC_OSD_ABI_VERSION (\d+)", hdr).group(1)) == 3
+    # struct layouts the binding mirrors (a silent drift here corrupts every OSD call)
+    import ctypes as C
+    assert C.sizeof(_lib.OsdParams) == 48 and _lib.OsdParams.d_aux.offset == 32 and _lib.OsdParams.y_frames.offset == 40
 
 
 @pytest.mark.parametrize("name,alist", [

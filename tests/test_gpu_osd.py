@@ -90,6 +90,30 @@ def test_front_end_ties_and_zeros(dec):
     assert np.array_equal(ns.cpu().numpy(), ns_o)
 
 
+def test_front_end_saturated_inputs(dec):
+    """Clipped / saturated values put most keys into ONE sort bucket (66 or more of the 128) while an exact zero sits in
+    the lowest: the in-bucket count then runs 128 entries past a bucket start (it used to read past the
+    64-entry pad and rank the zero at 128 -- a non-permutation).  Checked against the oracle's permutation."""
+    rng = np.random.default_rng(77)
+    y, _ = np_oracle.make_frames(dec.code.G, 2.5, 40, rng)
+    y = np.clip(y, -1.0, 1.0)
+    y[:, 5] = 0.0
+    y[1, 127] = 0.0                           # the smallest possible key: (|0.0| bits, 127 - 127)
+    y[2] = np.clip(y[2] * 8, -1.0, 1.0)       # nearly every value saturated
+    y[2, 5] = 0.0
+    y[3] = 1.0
+    y[3, 127] = 0.0                           # 127 equal keys in the top bucket, one zero
+    y[4] = np.where(rng.random(128) < 0.52, 1.0, y[4] * 0.01).astype(np.float32)
+    perm, parity, ns = dec.osd_front(to_dev(y, dec))
+    torch.cuda.synchronize()
+    got = perm.cpu().numpy()
+    assert all(sorted(p) == list(range(128)) for p in got.tolist())
+    perm_o, par_o, ns_o = _front_oracle(dec, y)
+    assert np.array_equal(got, perm_o)
+    assert np.array_equal(words_np(parity), par_o)
+    assert np.array_equal(ns.cpu().numpy(), ns_o)
+
+
 @pytest.mark.parametrize("order", [0, 1, 2])
 def test_conventional_osd_matches_oracle(dec, order):
     rng = np.random.default_rng(100 + order)
