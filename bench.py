@@ -61,9 +61,18 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default=os.environ.get("LDPC_BENCH_WORKLOAD", "nms10_osd2"), choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU and step (0 = the workload's default)")
     ap.add_argument("--batches", type=int, default=4, help="distinct pre-generated batches the timed loop rotates over")
-    ap.add_argument("--timing-every", type=int, default=8,
-                    help="bracket the hot kernels of every N-th timed step with HIP events (the roofline's live kernel durations); "
-                         "each step's five event records cost ~17 us of the 0.3 ms step, so not every step carries them")
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="time eager ldpc_pipeline_run calls instead of replaying the steps from a captured HIP graph "
+                         "(one graph = one rotation over the distinct batches; the eager form pays ~18 us of launch / ctypes "
+                         "time per 0.3 ms step)")
+    ap.add_argument("--graph-branches", type=int, default=3,
+                    help="parallel branches of the captured rotation: the distinct batches are independent, so batch i is captured on "
+                         "stream i mod N and the branches join at the end of the graph -- the ~5 us dispatch gap after every kernel "
+                         "and the kernel tails of one batch then hide behind the kernels of another (1 = one chain)")
+    ap.add_argument("--event-steps", type=int, default=24,
+                    help="steps of the SEPARATE pass, after the timed region, whose hot kernels are bracketed by HIP events "
+                         "(the roofline's live kernel durations; no event is recorded inside the timed region)")
+    ap.add_argument("--rank-timeout", type=float, default=900.0, help="--gpus N > 1 without a launcher: seconds the ranks may take")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap-pass", dest="overlap_pass", action="store_false",
                     help="skip the informative 3-stream pass that follows the timed region")
@@ -78,31 +87,68 @@ def parse_args(argv=None):
 # ---------------------------------------------------------------------------------------------------------
 # rank launcher: the parent never touches a GPU
 # ---------------------------------------------------------------------------------------------------------
-def spawn_ranks(args, argv):
-    import socket
+def visible_gpus():
+    """Number of GPUs this process may use, WITHOUT initialising a HIP runtime in it (the parent of the ranks must stay
+    GPU-free): the visibility variables if set, else a short-lived child process that asks torch."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:   # noqa: BLE001
+        return 0
 
-    import torch
+
+def spawn_ranks(args, argv, worker=None, have=None, poll=0.2):
+    """Start the N ranks as child processes and relay rank 0's JSON line.  Every child is polled: the first non-zero exit
+    (or the overall timeout) kills the others -- a rank that dies after init_process_group would otherwise leave rank 0
+    waiting in an RCCL barrier for ever, and the parent with it.  `worker` (argv prefix of a rank; default:
+    this file) and `have` exist for the CPU unit test of this function."""
+    import socket
     n = args.gpus
-    have = torch.cuda.device_count()     # (counts devices without initialising one)
+    have = visible_gpus() if have is None else have
     if have < n:
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible -- refusing to report a {n}-GPU number")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    worker = worker or [sys.executable, os.path.abspath(__file__)]
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    line = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
-    if any(codes) or not line:
+        procs.append(subprocess.Popen(worker + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)   # (drain rank 0's pipe while polling)
+    reader.start()
+    deadline = time.monotonic() + float(getattr(args, "rank_timeout", 900.0))
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            failed = f"ranks still running after {getattr(args, 'rank_timeout', 900.0):.0f} s"
+            break
+        time.sleep(poll)
+    if failed:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-        raise SystemExit(f"bench.py --gpus {n}: rank exit codes {codes}" + ("" if line else ", no JSON line from rank 0"))
+        for p in procs:
+            p.wait()
+        raise SystemExit(f"bench.py --gpus {n}: {failed}; the other ranks were killed")
+    reader.join(timeout=10)
+    line = [ln for ln in (out[0].decode() if out else "").splitlines() if ln.startswith("{")]
+    if not line:
+        raise SystemExit(f"bench.py --gpus {n}: no JSON line from rank 0")
     print(line[-1], flush=True)
 
 
@@ -129,9 +175,10 @@ def make_frames(dec, B, seed, snr_db=SNR_DB):
 
 
 def pmc_profile(kernel, workload, B):
-    """(HBM bytes per launch, VALU issue fraction) of `kernel` from the committed rocprofv3 PMC passes
+    """(HBM bytes per launch, VALU issue ratio, file) of `kernel` from the committed rocprofv3 PMC passes
     (scripts/profile_bench.sh + scripts/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE
-    doubled as the gfx950 guide prescribes) -- only when the profile was taken on this very workload; else nulls."""
+    doubled as the gfx950 guide prescribes) -- only when the profile was taken on this very workload; else nulls.
+    The PB-OSD entry of the bench line is three kernels: their traffic is summed, the ratio is the chunk kernel's."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_counters_*.json")), reverse=True):
         try:
@@ -140,7 +187,15 @@ def pmc_profile(kernel, workload, B):
             continue
         if prof.get("bench_workload") != workload or prof.get("frames_per_launch") != B:
             continue
-        for name, c in prof.get("per_launch_mean", {}).items():
+        rows = prof.get("per_launch_mean", {})
+        if kernel.startswith("pb_osd"):
+            sel = [c for n, c in rows.items() if "::pb_" in n and "clear" not in n and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
+            if sel:
+                main = [c for n, c in rows.items() if "pb_wave_kernel" in n]
+                return (sum((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 for c in sel),
+                        main[0].get("valu_issue_frac") if main else None, os.path.relpath(path, ROOT))
+            continue
+        for name, c in rows.items():
             if kernel in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 issue = c.get("valu_issue_frac")
                 if issue is None and c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c:
@@ -149,7 +204,41 @@ def pmc_profile(kernel, workload, B):
     return None, None, None
 
 
-def cpu_baseline(code_G, code_H, order, alpha, seconds_target=12.0):
+def cpu_counts(code_G, code_H, y, cw, alpha, order, algo=0, snr_db=SNR_DB, iters=T_ITERS):
+    """One batch through the CPU port (oracle/ldpc_oracle.c): NMS, then the OSD of the workload on the syndrome failures.
+    int64[5] = {frames, NMS frame errors, undetected NMS errors, syndrome failures, OSD failures}.  The checker, timed
+    beside the GPU path -- never part of it (only bench.py's cpu_baseline leg, scripts/snr_sweep.py --cpu-check and the
+    tests may call into oracle/)."""
+    import numpy as np
+
+    from oracle import c_oracle
+    soft = c_oracle.nms(code_H, y, iters, alpha)
+    _, fail, cnt = c_oracle.evaluate(code_H, soft, cw)
+    nfail = int(cnt["synd_fail"])
+    wrong = nfail
+    if order is not None:
+        idx = np.flatnonzero(fail)
+        wrong = 0
+        if idx.size:
+            if algo == 2:
+                ok = c_oracle.pb_osd(code_G, y[idx], cw[idx], order, snr_db)["correct"]
+            elif algo == 1:
+                ok = c_oracle.fs_osd(code_G, y[idx], cw[idx], order)["correct_ref"]
+            else:
+                ok = c_oracle.conv_osd(code_G, y[idx], cw[idx], order)["correct"]
+            wrong = int((~ok).sum())
+    return np.array([y.shape[0], cnt["frame_err"], cnt["undetected"], nfail, wrong], dtype=np.int64)
+
+
+def host_cores():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(cores, 16))   # a one-GPU box shares its host: 16 cores per GPU
+
+
+def cpu_baseline(code_G, code_H, order, alpha, algo=0, snr_db=SNR_DB, seconds_target=12.0):
     """The C oracle (scalar port of the same math) on this host: frames are split over the host cores this
     process may use (the C calls release the GIL), bounded sample; the one-thread rate and the sample's FER are
     reported alongside, plus the dense NumPy mirror of the reference's own formulation on one core."""
@@ -157,69 +246,61 @@ def cpu_baseline(code_G, code_H, order, alpha, seconds_target=12.0):
 
     import numpy as np
 
-    from oracle import c_oracle, np_oracle
+    from oracle import np_oracle
     rng = np.random.default_rng(20241020)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))   # a one-GPU box shares its host: 16 cores per GPU
+    cores = host_cores()
+    osd_name = {0: "OSD", 1: "FS-OSD", 2: "PB-OSD"}[algo]
 
     def once(yb, cb):
-        soft = c_oracle.nms(code_H, yb, T_ITERS, alpha)
-        _, fail, cnt = c_oracle.evaluate(code_H, soft, cb)
-        wrong = 0
-        nfail = int(cnt["synd_fail"])
-        if order is not None:
-            idx = np.flatnonzero(fail)
-            if idx.size:
-                wrong = int((~c_oracle.conv_osd(code_G, yb[idx], cb[idx], order)["correct"]).sum())
-        else:
-            wrong = nfail
-        return np.array([yb.shape[0], cnt["frame_err"], cnt["undetected"], nfail, wrong], dtype=np.int64)
+        return cpu_counts(code_G, code_H, yb, cb, alpha, order, algo, snr_db)
 
-    frames = 2000
-    y, cw = np_oracle.make_frames(code_G, SNR_DB, frames, rng)
+    frames = 2000 if algo == 0 else 300        # (the port's PB-OSD replays the frontier list literally: ~1 ms per long search)
+    y, cw = np_oracle.make_frames(code_G, snr_db, frames, rng)
     t0 = time.perf_counter()
     once(y, cw)
     rate1 = frames / (time.perf_counter() - t0)                        # one thread, also the warm-up
-    per = int(max(1000, min(100000, rate1 * seconds_target)))            # frames per worker
-    y, cw = np_oracle.make_frames(code_G, SNR_DB, per * cores, rng)
+    per = int(max(200, min(100000, rate1 * seconds_target)))             # frames per worker
+    y, cw = np_oracle.make_frames(code_G, snr_db, per * cores, rng)
     parts = [(y[i * per:(i + 1) * per], cw[i * per:(i + 1) * per]) for i in range(cores)]
     with concurrent.futures.ThreadPoolExecutor(max_workers=cores) as ex:
         t0 = time.perf_counter()
         c = sum(ex.map(lambda p: once(*p), parts))
         dt = time.perf_counter() - t0
     # "reference-equivalent CPU" (SURVEY 8(d)(i)): the reference's dense [B,64,128] formulation (ms_test.py:124-228) and
-    # its per-frame int-matmul OSD (convention_osd.py:49-76), restated in NumPy, one core
-    nref = 400
-    yr, cr = y[:nref], cw[:nref]
-    t0 = time.perf_counter()
-    soft = np_oracle.nms_dense(yr, code_H, T_ITERS, alpha)[-1]
-    t_nms = time.perf_counter() - t0
-    _, _, _, failed = np_oracle.evaluate(soft, cr, code_H)
-    t0 = time.perf_counter()
-    nosd = 0
-    if order is not None:
-        teps = np_oracle.tep_matrix(64, order)
-        for i in list(failed)[:40]:
-            yp, lp, Gp, _, _ = np_oracle.swapped_info(yr[i], cr[i], code_G)
-            np_oracle.convention_osd(yp, lp, Gp, order, teps)
-            nosd += 1
-    t_osd = (time.perf_counter() - t0) / max(nosd, 1) * len(failed)      # scaled to all failures of the sample
-    ref_rate = nref / (t_nms + (t_osd if order is not None else 0.0))
+    # its per-frame int-matmul OSD (convention_osd.py:49-76), restated in NumPy, one core (conventional OSD only)
+    ref = None
+    if algo == 0:
+        nref = 400
+        yr, cr = y[:nref], cw[:nref]
+        t0 = time.perf_counter()
+        soft = np_oracle.nms_dense(yr, code_H, T_ITERS, alpha)[-1]
+        t_nms = time.perf_counter() - t0
+        _, _, _, failed = np_oracle.evaluate(soft, cr, code_H)
+        t0 = time.perf_counter()
+        nosd = 0
+        if order is not None:
+            teps = np_oracle.tep_matrix(64, order)
+            for i in list(failed)[:40]:
+                yp, lp, Gp, _, _ = np_oracle.swapped_info(yr[i], cr[i], code_G)
+                np_oracle.convention_osd(yp, lp, Gp, order, teps)
+                nosd += 1
+        t_osd = (time.perf_counter() - t0) / max(nosd, 1) * len(failed)      # scaled to all failures of the sample
+        ref_rate = nref / (t_nms + (t_osd if order is not None else 0.0))
+        ref = dict(value=ref_rate, unit="frames/s", cores=1, kind="port",
+                   sample=f"dense NumPy mirror of ms_test.py:124-228 on {nref} frames ({nref / t_nms:.0f} frames/s)"
+                          + (f" + NumPy convention_osd_main order {order} timed on {nosd} of the {len(failed)} "
+                             f"failures ({t_osd / max(len(failed), 1) * 1e3:.0f} ms per failed frame)" if order is not None else ""))
     e2e = int(c[4] + c[2]) if order is not None else int(c[1])
-    return dict(value=per * cores / dt, unit="frames/s", cores=cores, kind="port",
-                sample=f"{per * cores} frames at {SNR_DB} dB through oracle/ldpc_oracle.c (gcc -O2, scalar code, {cores} "
-                       f"threads of {per} frames): NMS-{T_ITERS}"
-                       + (f" + OSD-{order} on the syndrome failures" if order is not None else "")
-                       + f", {dt:.1f} s; one thread alone: {rate1:.0f} frames/s",
-                frames=int(c[0]), fer_nms=float(c[1] / c[0]), syndrome_fail_rate=float(c[3] / c[0]),
-                fer_end_to_end=float(e2e / c[0]), frame_errors_end_to_end=e2e,
-                reference_equivalent=dict(value=ref_rate, unit="frames/s", cores=1, kind="port",
-                                          sample=f"dense NumPy mirror of ms_test.py:124-228 on {nref} frames ({nref / t_nms:.0f} frames/s)"
-                                                 + (f" + NumPy convention_osd_main order {order} timed on {nosd} of the {len(failed)} "
-                                                    f"failures ({t_osd / max(len(failed), 1) * 1e3:.0f} ms per failed frame)" if order is not None else "")))
+    out = dict(value=per * cores / dt, unit="frames/s", cores=cores, kind="port",
+               sample=f"{per * cores} frames at {snr_db} dB through oracle/ldpc_oracle.c (gcc -O2, scalar code, {cores} "
+                      f"threads of {per} frames): NMS-{T_ITERS}"
+                      + (f" + {osd_name}-{order} on the syndrome failures" if order is not None else "")
+                      + f", {dt:.1f} s; one thread alone: {rate1:.0f} frames/s",
+               frames=int(c[0]), fer_nms=float(c[1] / c[0]), syndrome_fail_rate=float(c[3] / c[0]),
+               fer_end_to_end=float(e2e / c[0]), frame_errors_end_to_end=e2e)
+    if ref is not None:
+        out["reference_equivalent"] = ref
+    return out
 
 
 def run_rank(args):
@@ -263,18 +344,61 @@ def run_rank(args):
     for k in range(max(args.warmup, nb)):
         run_step(k)
     torch.cuda.synchronize()
+    # The timed region replays the steps from a captured HIP graph: one graph = one rotation over the nb distinct batches
+    # (nb x the launches of ldpc_pipeline_run), so a 0.3 ms step no longer carries ~18 us of launch and ctypes time per
+    # step (the driver-timed step was 6 % above the kernel sum).  Steps beyond whole rotations, several
+    # streams, or a failed capture run eagerly; the JSON line says which.
+    graph, timed_region = None, "eager ldpc_pipeline_run calls"
+    if args.graph and len(streams) == 1 and args.steps >= nb:
+        try:
+            side = torch.cuda.Stream()
+            nbr = max(1, min(args.graph_branches, nb))
+            branch = [side] + [torch.cuda.Stream() for _ in range(1, nbr)]
+
+            def rotation():
+                for st in branch[1:]:
+                    st.wait_stream(side)                 # fork
+                for i, p in enumerate(pipes):
+                    with torch.cuda.stream(branch[i % nbr]):
+                        p.run()
+                for st in branch[1:]:
+                    side.wait_stream(st)                 # join
+
+            with torch.cuda.stream(side):
+                for st in branch:                        # every capture stream's OSD workspace (PB-OSD: lists, tables) is sized first
+                    with torch.cuda.stream(st):
+                        if order is not None:
+                            dec.osd_reserve_stream(B, pipes[0]._p.osd)
+                rotation()                               # (one eager rotation on the capture streams: nothing is allocated under capture)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                rotation()
+            graph = g
+            for _ in range(max(1, -(-args.warmup // nb))):      # the warm-up steps once more, as replays (a graph's first launch uploads it)
+                g.replay()
+            torch.cuda.synchronize()
+            timed_region = (f"HIP graph replay, {nb} steps (one rotation over the distinct batches) per graph launch, "
+                            f"{nbr} parallel branch(es)")
+        except Exception as exc:   # noqa: BLE001
+            graph = None
+            timed_region = f"eager ldpc_pipeline_run calls (graph capture failed: {type(exc).__name__})"
+            torch.cuda.synchronize()
     for p in pipes:
         p.reset_counters()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    timing_every = max(1, args.timing_every)
-    timed_slots = sorted({(k // timing_every) % TIMING_SLOTS for k in range(0, args.steps, timing_every)})
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        # library-side HIP events around the hot kernels of every `timing_every`-th step (five event records cost 17 us per step)
-        run_step(k, slot=((k // timing_every) % TIMING_SLOTS) if k % timing_every == 0 else -1)
+    if graph is not None:
+        for _ in range(args.steps // nb):
+            graph.replay()
+        for k in range(args.steps - args.steps % nb, args.steps):
+            run_step(k)
+    else:
+        for k in range(args.steps):
+            run_step(k)
     for st in streams[1:]:
         torch.cuda.current_stream().wait_stream(st)
     total = pipes[0].counters().clone()
@@ -299,6 +423,14 @@ def run_rank(args):
         if runs:
             distinct += p.counters() // runs
     d = allreduce_counters(distinct).cpu().numpy().astype(np.int64)
+
+    # kernel durations for the roofline: a SEPARATE pass with the library's HIP events around the hot kernels (none inside
+    # the timed region; recording five events costs ~17 us of a 0.3 ms step)
+    nev = max(1, min(args.event_steps, TIMING_SLOTS))
+    for k in range(nev):
+        pipes[k % nb].run(timing_slot=k)
+    torch.cuda.synchronize()
+    timed_slots = list(range(nev))
 
     # informative second pass (not the headline): the same steps with three batches in flight on three streams,
     # where the NMS of one batch overlaps the OSD kernels (and the kernel tails) of another
@@ -332,6 +464,7 @@ def run_rank(args):
     value = frames_total / elapsed
     res = {
         "metric": "decoded frames/sec + FER, (128,64) LDPC NMS-10+OSD-2 @ 2.5 dB",
+        "timed_region": timed_region,
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -357,31 +490,34 @@ def run_rank(args):
     fer_ok = True
     if rank == 0:
         # roofline of the dominant kernel from the HIP events recorded on the launch stream
-        tm = np.array([pipes[0].timing(k) for k in timed_slots])
+        tm = np.array([pipes[0].timing(k) for k in timed_slots])   # (slots are per context: any pipeline reads them)
         nms_name = {1: "nms_generic_kernel", 2: "nms_qc16_kernel"}[dec.nms_kernel]
         kern = {nms_name: (float(tm[:, 0].mean()), NMS_BYTES_PER_FRAME * B)}
         if order is not None:
             f_per_step = c[5] / (args.steps * world)
             if tm[:, 1].mean() > 0.02:   # two-kernel OSD (front end + search through the workspace)
                 kern["osd_front_kernel"] = (float(tm[:, 1].mean()), (512 + 640) * f_per_step)
-                sname = {1: "osd_fs_kernel", 2: "pb_osd (three kernels)"}.get(algo, "osd_search2r_kernel" if order == 2 else "osd_search_kernel")
+                sname = {1: "osd_fs_kernel", 2: "pb_osd (singles + chunk + latency-shaped kernels)"}.get(algo, "osd_search2r_kernel" if order == 2 else "osd_search_kernel")
                 kern[sname] = (float(tm[:, 2].mean()), (1152 + 24) * f_per_step)
             else:                        # OSD through the context workspace: one combined duration
                 kern["osd_front+search"] = (float(tm[:, 2].mean()), OSD_BYTES_PER_FRAME * f_per_step)
         name = max(kern, key=lambda k: kern[k][0])
         ms, nbytes = kern[name]
         achieved = nbytes / (ms * 1e-3) / 1e9
-        traffic, issue, prof_path = pmc_profile(name, args.workload, B)
+        traffic, issue, prof_path = pmc_profile(name, args.workload if args.snr == SNR_DB else f"{args.workload}_snr{args.snr}", B)
         res["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "issue_frac": issue, "pmc_profile": prof_path,
-                           "avg_launch_ms": ms, "timed_launches": len(timed_slots), "algorithmic_bytes_per_launch": float(nbytes),
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_issue_ratio": issue, "pmc_profile": prof_path,
+                           "avg_launch_ms": ms, "timed_launches": len(timed_slots), "timed_in": "separate event-bracketed pass after the timed region",
+                           "algorithmic_bytes_per_launch": float(nbytes),
                            "all_kernels_ms": {k: v[0] for k, v in kern.items()},
                            "all_kernels_GBps": {k: v[1] / (v[0] * 1e-3) / 1e9 for k, v in kern.items()},
-                           "note": "no contraction on this path (no MFMA); the kernels are instruction-issue bound: issue_frac = "
-                                   "vector-issue cycles / cycles the 1024 SIMDs had during the launch (committed PMC pass, "
-                                   "SQ_ACTIVE_INST_VALU); HBM fraction reported as mandated -- see DESIGN.md 5"}
+                           "note": "no contraction on this path (no MFMA); the kernels are instruction-issue bound: valu_issue_ratio = "
+                                   "SQ_ACTIVE_INST_VALU (= one 4-cycle issue slot per vector instruction, it equals SQ_INSTS_VALU) / "
+                                   "the SIMD quad-cycles of the launch (GRBM_GUI_ACTIVE / 8 XCDs / 4 x 1024 SIMDs), from the committed "
+                                   "PMC pass; a RATIO, not a fraction: instructions of the 2-cycle class (add, mul, fma, xor) make it "
+                                   "exceed 1 when the vector ALUs never idle; HBM fraction reported as mandated -- see DESIGN.md 5"}
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(dec.code.G, dec.code.H, order, alpha)
+            cpu = cpu_baseline(dec.code.G, dec.code.H, order, alpha, algo=algo, snr_db=args.snr)
             res["cpu_baseline"] = cpu
             # north_star acceptance: FER within +-5 % (relative) of the float CPU path of the same run, judged when both
             # sides hold >= 1600 frame errors; sigma of the ratio of two Poisson counts

@@ -27,7 +27,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_SO)
+        L = C.CDLL(os.environ.get("LDPC_ORACLE_LIB") or _SO)     # (LDPC_ORACLE_LIB: the sanitizer build of build.py --asan)
         i32p, f32p, u8p, i64p = (C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_uint8),
                                  C.POINTER(C.c_int64))
         L.orc_gf2elim.argtypes = [i32p, C.c_int, C.c_int, i32p, i32p]

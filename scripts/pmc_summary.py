@@ -9,8 +9,13 @@ Reads every <tag>_<PASS>/**/*_counter_collection.csv (one row per dispatch and c
 coalesced reads by 2x on gfx950, MI355X_MICROARCH.md HBM -- bench.py doubles it); SQ_* cycle counters are
 quad-cycles summed over the chip; GRBM_GUI_ACTIVE is summed over the 8 XCDs.  Adds per kernel
     valu_issue_frac = SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 / 4 * 1024 SIMDs)
-(vector-issue quad-cycles over the quad-cycles the 1024 SIMDs had during the launch; the counter also counts
-issue cycles that overlap between waves, so a saturated kernel can read slightly above 1).
+-- a RATIO, not a utilisation: SQ_ACTIVE_INST_VALU counts ONE quad-cycle issue slot per vector instruction and wave (it
+equals SQ_INSTS_VALU in every pass taken here), the denominator is the quad-cycles the 1024 SIMDs had during the launch
+(GRBM_GUI_ACTIVE / 8 is the launch's duration in shader clocks: 2.3 M / 8 = 287 k cycles for the 115.7 us NMS launch =
+2.48 GHz).  Instructions of the 2-cycle class (v_add/mul/fma/xor: profiles/r01/ubench_valu_issue*.txt) take less than
+their slot, so a kernel whose vector ALUs never idle reads ABOVE 1 (NMS: 1.12; ADVICE r02 asked what the 12 % are).
+For kernels that run fewer waves than the chip holds, SQ_WAIT_ANY / SQ_WAVE_CYCLES (share of a wave's life parked on
+s_waitcnt) and SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES are printed too.
 """
 from __future__ import annotations
 
@@ -54,6 +59,11 @@ def main():
         g, a = per[kern].get("GRBM_GUI_ACTIVE"), per[kern].get("SQ_ACTIVE_INST_VALU")
         if g and a is not None:
             per[kern]["valu_issue_frac"] = a / (g / 8.0 / 4.0 * 1024.0)
+        wc = per[kern].get("SQ_WAVE_CYCLES")
+        if wc:
+            for name, key in (("SQ_WAIT_ANY", "wait_any_share"), ("SQ_WAIT_INST_ANY", "wait_inst_share")):
+                if name in per[kern]:
+                    per[kern][key] = per[kern][name] / wc
     bench_line = None
     log = args.prefix + "_stats.log"
     if os.path.exists(log):

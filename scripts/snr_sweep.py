@@ -8,7 +8,10 @@ across the GPUs of a node and ONE RCCL all-reduce of the counters per SNR point.
 Prints one JSON line per SNR point (rank 0): FER_NMS, FER_OSD|fail, their product (what the reference's
 recipe multiplies by hand, `Training and Testing recipe.txt:18`), end-to-end FER, mean TEPs, frames/s.
 The reference sweeps 2.0-3.0 dB with order 3 and stops each point at 100 OSD failures
-(PB_OSD/globalmap.py:42-43); here every point decodes the requested number of frames.
+(PB_OSD/globalmap.py:42-43): `--stop-errors 100` does the same (one 64-byte all-reduce per macro-batch, every rank
+leaves on the same macro-batch); by default every point decodes the requested number of frames.
+`--cpu-check` decodes a bounded sample of every point with the CPU port (oracle/ldpc_oracle.c, the checker) on rank 0 and
+prints `fer_vs_cpu` beside the GPU figures: +-5 % judged when both sides hold >= 1600 frame errors, else "not judged".
 """
 import argparse
 import json
@@ -25,7 +28,7 @@ sys.path.insert(0, ROOT)
 from short_ldpc_decoding_osd_amd import Code, _lib  # noqa: E402
 from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline  # noqa: E402
 from short_ldpc_decoding_osd_amd.runtime import Decoder  # noqa: E402
-from short_ldpc_decoding_osd_amd.sharding import allreduce_counters, combine_fer, rank_seed, shard_range  # noqa: E402
+from short_ldpc_decoding_osd_amd.sharding import combine_fer, end_to_end_errors, rank_seed, shard_range, sweep_point  # noqa: E402
 from short_ldpc_decoding_osd_amd.weights import softplus32  # noqa: E402
 
 ALGOS = {"conv": _lib.OSD_CONVENTIONAL, "fs": _lib.OSD_FS, "pb": _lib.OSD_PB}
@@ -39,6 +42,34 @@ def frames_on_device(dec, B, snr_db, gen):
     return y, dec.pack_bits(cw.to(torch.uint8))
 
 
+def cpu_check(code, alpha, args, snr, gpu_errors, gpu_frames):
+    """The same SNR point through the CPU port on a bounded sample (all host cores of this rank's share): FER of both
+    sides and the +-5 % judgement of BASELINE.json's north_star (>= 1600 frame errors on both sides, else not judged)."""
+    import concurrent.futures
+
+    import bench
+    from oracle import np_oracle
+    algo = ALGOS[args.osd]
+    rng = np.random.default_rng(20241020 + int(round(snr * 100)))
+    cores = bench.host_cores()
+    probe = 200
+    y, cw = np_oracle.make_frames(code.G, snr, probe, rng)
+    t0 = time.perf_counter()
+    bench.cpu_counts(code.G, code.H, y, cw, alpha, args.order, algo, snr, args.iters)
+    per = int(max(100, min(200000, probe / (time.perf_counter() - t0) * args.cpu_seconds)))
+    y, cw = np_oracle.make_frames(code.G, snr, per * cores, rng)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=cores) as ex:
+        c = sum(ex.map(lambda i: bench.cpu_counts(code.G, code.H, y[i * per:(i + 1) * per], cw[i * per:(i + 1) * per], alpha,
+                                                  args.order, algo, snr, args.iters), range(cores)))
+    ec = int(c[4] + c[2]) if args.order is not None else int(c[1])
+    fg, fc = gpu_errors / max(gpu_frames, 1), ec / max(int(c[0]), 1)
+    enough = gpu_errors >= 1600 and ec >= 1600
+    rel = fg / fc - 1.0 if fc > 0 else float("nan")
+    return {"gpu_fer_end_to_end": fg, "cpu_fer_end_to_end": fc, "cpu_frames": int(c[0]), "cpu_frame_errors": ec, "gpu_frame_errors": int(gpu_errors),
+            "fer_rel_diff_vs_cpu": rel, "two_sigma_of_rel_diff": 2.0 * float(np.sqrt(1.0 / max(gpu_errors, 1) + 1.0 / max(ec, 1))),
+            "judged": bool(enough), "within_5_percent": bool(abs(rel) <= 0.05) if enough else "not judged"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--snr", nargs=3, default=["1.0", "3.5", "6"], metavar=("LO", "HI", "NUM"))
@@ -49,6 +80,12 @@ def main():
     ap.add_argument("--order", type=int, default=3)
     ap.add_argument("--weight", type=float, default=-0.048, help="stored (pre-softplus) NMS-1 weight")
     ap.add_argument("--values", default=None, help="par/values.txt of the training stage (overrides --weight)")
+    ap.add_argument("--stop-errors", type=int, default=0,
+                    help="end an SNR point once this many end-to-end frame errors were seen over all ranks (the reference's "
+                         "termination_num_threshlod, PB_OSD/globalmap.py:43: 100); 0 = decode --frames frames")
+    ap.add_argument("--cpu-check", action="store_true",
+                    help="rank 0: decode a bounded sample of every SNR point with the CPU port too and print fer_vs_cpu")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="--cpu-check: CPU time budget per SNR point")
     args = ap.parse_args()
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
@@ -73,27 +110,30 @@ def main():
     if mine >= args.batch:
         dec.osd_reserve(args.batch)
     torch.cuda.synchronize()
+    with_osd = args.order is not None
+    max_batches = -(-shard_range(args.frames, 0, world)[1] // args.batch)       # rank 0 owns the largest shard
     for snr in np.linspace(float(args.snr[0]), float(args.snr[1]), int(args.snr[2])):
         snr = round(float(snr), 2)
-        total = torch.zeros(8, dtype=torch.int64, device=dec.device)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        done = 0
-        while done < mine:
-            B = min(args.batch, mine - done)
+
+        def decode_batch(B, snr=snr):
             y, lab = frames_on_device(dec, B, snr, gen)
             pipe = BatchPipeline(dec, B, args.iters, alpha, osd_order=args.order, osd_algo=ALGOS[args.osd], snr_db=snr,
                                  want_soft=False, keep_front=False).bind(y, lab)
             pipe.run()
-            total += pipe.counters()
-            done += B
-        total = allreduce_counters(total)                       # the one exchange step per SNR point
+            return pipe.counters()
+
+        total, ran = sweep_point(decode_batch, mine, args.batch, max_batches, args.stop_errors, with_osd)   # the point's exchange step(s)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if rank == 0:
-            out = combine_fer(total.cpu().numpy())
-            out.update(snr_db=snr, osd=args.osd, order=args.order, alpha=alpha, n_gpus=world,
-                       frames_per_s_incl_generation=args.frames / dt)
+            c = total.cpu().numpy()
+            out = combine_fer(c)
+            out.update(snr_db=snr, osd=args.osd, order=args.order, alpha=alpha, n_gpus=world, macro_batches=ran,
+                       stop_errors=args.stop_errors, frames_per_s_incl_generation=int(c[0]) / dt)
+            if args.cpu_check:
+                out["fer_vs_cpu"] = cpu_check(dec.code, alpha, args, snr, end_to_end_errors(c, with_osd), int(c[0]))
             print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

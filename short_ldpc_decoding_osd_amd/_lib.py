@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libldpcosd.so")
+# LDPC_OSD_LIB: another build of the same ABI (the host-only sanitizer build of `build.py --asan`, whose device entry
+# points are stubs that fail)
+LIB_PATH = os.environ.get("LDPC_OSD_LIB") or os.path.join(_HERE, "libldpcosd.so")
 
 # every symbol include/ldpc_osd.h declares (tests check the list against the header)
 SYMBOLS = (

@@ -1,6 +1,13 @@
 """Builds libldpcosd.so in-tree with hipcc for gfx950 (MI355X).  No GPU is needed to build.
 
     python -m short_ldpc_decoding_osd_amd.build [--force]
+    python -m short_ldpc_decoding_osd_amd.build --asan [--run]
+
+--asan: CPU sanitizer build ("race detection / sanitizers"): the library's HOST code (csrc/ldpc_host.cpp: alist
+parser, G construction, GF(2) elimination, TEP tables, CRC-32C) and the C oracle under -fsanitize=address,undefined, as
+libldpcosd_asan.so / oracle/_build/libldpc_oracle_asan.so; --run then runs the host-side test files against them
+(LDPC_OSD_LIB / LDPC_ORACLE_LIB select the libraries, the sanitizer runtime is preloaded).  Device code is never
+sanitized: GPU AddressSanitizer runs are not available on this pool.
 """
 from __future__ import annotations
 
@@ -66,5 +73,47 @@ def build(force=False, verbose=False):
     return LIB
 
 
+ASAN_LIB = os.path.join(HERE, "libldpcosd_asan.so")
+ASAN_TESTS = ["tests/test_cabi.py", "tests/test_hosd_host.py", "tests/test_tfrecord.py", "tests/test_weights.py", "tests/test_oracle_golden.py"]
+
+
+def build_asan(verbose=False):
+    """Host-only sanitizer build of the library and the oracle; returns (library, oracle library, sanitizer runtime)."""
+    root = os.path.dirname(HERE)
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+    cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + san + [
+        os.path.join(CSRC, "ldpc_host.cpp"), os.path.join(CSRC, "ldpc_sanitizer_stubs.cpp"), "-o", ASAN_LIB,
+        "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"]
+    oracle_so = os.path.join(root, "oracle", "_build", "libldpc_oracle_asan.so")
+    os.makedirs(os.path.dirname(oracle_so), exist_ok=True)
+    cmd2 = ["gcc", "-std=c11", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off", "-fno-fast-math"] + san + [
+        os.path.join(root, "oracle", "ldpc_oracle.c"), "-o", oracle_so, "-lm"]
+    for c in (cmd, cmd2):
+        if verbose:
+            print(" ".join(c), flush=True)
+        p = subprocess.run(c, capture_output=True, text=True)
+        if p.returncode:
+            raise RuntimeError("sanitizer build failed:\n" + " ".join(c) + "\n" + p.stdout + p.stderr)
+    rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    return ASAN_LIB, oracle_so, rt
+
+
+def run_asan_tests(extra=()):
+    """pytest over the host-side test files with the sanitized libraries; returns the subprocess result."""
+    lib, oracle_so, rt = build_asan()
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, LDPC_OSD_LIB=lib, LDPC_ORACLE_LIB=oracle_so, LD_PRELOAD=rt,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    return subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + ASAN_TESTS + list(extra),
+                          cwd=root, env=env, capture_output=True, text=True)
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--asan" in sys.argv:
+        print(build_asan(verbose=True))
+        if "--run" in sys.argv:
+            r = run_asan_tests()
+            print(r.stdout[-3000:], r.stderr[-3000:])
+            sys.exit(r.returncode)
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -49,15 +49,20 @@ int ldpc_ctx_create(const ldpc_code *code, int32_t device, ldpc_ctx **out)
         if ((rc = upload(code->var_edge, &ctx->d_var_edge))) break;
         if ((rc = probe_dpp(&ctx->dpp_ror_up, &ctx->dpp_wave_rol_dir))) break;
         // event pool of ldpc_pipeline_run's timing slots: created (and recorded once: the first record of an
-        // event sets up its signal and is slow) here, so that decode calls never change the context
+        // event sets up its signal and is slow) here, so that decode calls never create anything.  The warm-up
+        // records go to a private stream -- the legacy NULL stream would synchronise with every blocking stream
+        // of the process and break a capture in progress elsewhere.
         ctx->timing = new hipEvent_t[LDPC_TIMING_SLOTS * 6]();
+        hipStream_t warm = nullptr;
+        if (hipStreamCreateWithFlags(&warm, hipStreamNonBlocking) != hipSuccess) { rc = fail(LDPC_E_HIP, "ldpc_ctx_create: stream creation failed"); break; }
         for (int i = 0; i < LDPC_TIMING_SLOTS * 6 && !rc; ++i) {
             hipError_t he = hipEventCreate(&ctx->timing[i]);
-            if (he == hipSuccess) he = hipEventRecord(ctx->timing[i], nullptr);
+            if (he == hipSuccess) he = hipEventRecord(ctx->timing[i], warm);
             if (he != hipSuccess) rc = hip_fail(he, "timing event pool");
         }
+        if (!rc && hipStreamSynchronize(warm) != hipSuccess) rc = fail(LDPC_E_HIP, "ldpc_ctx_create: stream sync failed");
+        (void)hipStreamDestroy(warm);
         if (rc) break;
-        if (hipStreamSynchronize(nullptr) != hipSuccess) { rc = fail(LDPC_E_HIP, "ldpc_ctx_create: stream sync failed"); break; }
         if ((rc = osd_ctx_init(ctx))) break;
         if ((rc = hosd_ctx_init(ctx))) break;
     } while (0);
@@ -104,15 +109,19 @@ int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
     if (!p->d_hard || !p->d_fail) return fail(LDPC_E_ARG, "ldpc_pipeline_run: d_hard and d_fail are required");
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t *ev = nullptr;
+    unsigned *rec = nullptr;            // which of the slot's events THIS run records (ldpc_pipeline_timing reads only those)
     if (p->timing_slot >= 0) {
         if (p->timing_slot >= LDPC_TIMING_SLOTS || !ctx->timing) return fail(LDPC_E_ARG, "ldpc_pipeline_run: timing_slot %d", p->timing_slot);
         ev = ctx->timing + p->timing_slot * 6;
+        rec = &ctx->timing_recorded[p->timing_slot];
+        *rec = 0;
     }
+#define LDPC_EV(i) do { if (ev) { LDPC_HIP(hipEventRecord(ev[i], s)); *rec |= 1u << (i); } } while (0)
     int rc;
-    if (ev) LDPC_HIP(hipEventRecord(ev[0], s));
+    LDPC_EV(0);
     if ((rc = ldpc_nms_decode(ctx, p->d_llr, p->B, p->T, p->alpha, p->w_in, p->w_out, p->d_soft, nullptr, p->d_hard,
                               p->d_fail, p->nms_kernel, stream))) return rc;
-    if (ev) LDPC_HIP(hipEventRecord(ev[1], s));
+    LDPC_EV(1);
     const bool want_eval = p->d_label_bits && p->d_nms_counts;
     if (p->osd_enable) {
         if (!p->d_index || !p->d_count || !p->d_cw)
@@ -121,22 +130,27 @@ int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
             if ((rc = eval_and_compact(ctx, p->d_hard, p->d_label_bits, p->d_fail, p->B, p->d_nms_counts, p->d_index,
                                        p->d_count, s))) return rc;
         } else if ((rc = ldpc_compact(ctx, p->d_fail, p->B, p->d_index, p->d_count, stream))) return rc;
-        if (ev) LDPC_HIP(hipEventRecord(ev[2], s));
+        LDPC_EV(2);
         if (p->d_perm && p->d_parity) {   // caller wants the front-end results: two kernels
             if ((rc = ldpc_osd_front(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, nullptr, stream))) return rc;
-            if (ev) LDPC_HIP(hipEventRecord(ev[3], s));
-            const bool counted = p->d_label_bits && p->d_osd_counts;   // the search kernel counts its own successes where it can
+            LDPC_EV(3);
+            // the search kernel counts its own successes where it can (order-2 scan); otherwise the counting launch follows
+            // the search's closing event, so that ms[2] is the search alone for every algorithm
+            const bool counted = p->d_label_bits && p->d_osd_counts;
+            bool fused = false;
             if ((rc = osd_search_counted(ctx, p->d_llr, p->d_index, p->d_count, p->B, p->d_perm, p->d_parity, &p->osd, p->d_cw,
                                          p->d_metric, p->d_best, p->d_ntep, counted ? p->d_label_bits : nullptr,
-                                         counted ? p->d_osd_counts : nullptr, s))) return rc;
-            if (ev) LDPC_HIP(hipEventRecord(ev[4], s));
+                                         counted ? p->d_osd_counts : nullptr, s, &fused))) return rc;
+            LDPC_EV(4);
+            if (counted && !fused &&
+                (rc = ldpc_osd_counts(ctx, p->d_cw, p->d_label_bits, p->d_index, p->d_count, p->d_ntep, p->B, p->d_osd_counts, stream))) return rc;
             return LDPC_OK;
         } else {                          // ldpc_osd_decode on the context's workspace
-            if (ev) LDPC_HIP(hipEventRecord(ev[3], s));
+            LDPC_EV(3);
             if ((rc = ldpc_osd_decode(ctx, p->d_llr, p->d_index, p->d_count, p->B, &p->osd, p->d_cw, p->d_metric, p->d_best,
                                       p->d_ntep, stream))) return rc;
         }
-        if (ev) LDPC_HIP(hipEventRecord(ev[4], s));
+        LDPC_EV(4);
         if (p->d_label_bits && p->d_osd_counts &&
             (rc = ldpc_osd_counts(ctx, p->d_cw, p->d_label_bits, p->d_index, p->d_count, p->d_ntep, p->B, p->d_osd_counts,
                                   stream))) return rc;
@@ -150,10 +164,12 @@ int ldpc_pipeline_timing(ldpc_ctx *ctx, int32_t slot, float *ms)
     if (!ctx || !ms || slot < 0 || slot >= LDPC_TIMING_SLOTS || !ctx->timing)
         return fail(LDPC_E_ARG, "ldpc_pipeline_timing: no timed run in slot %d", slot);
     hipEvent_t *ev = ctx->timing + slot * 6;
+    const unsigned rec = ctx->timing_recorded[slot];     // events of the LAST run that used the slot (all were recorded once at creation)
     ms[0] = ms[1] = ms[2] = 0.0f;
+    if ((rec & 3u) != 3u) return fail(LDPC_E_ARG, "ldpc_pipeline_timing: no timed run in slot %d", slot);
     LDPC_HIP(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
-    if (hipEventElapsedTime(&ms[1], ev[2], ev[3]) != hipSuccess) { ms[1] = 0.0f; (void)hipGetLastError(); }
-    if (hipEventElapsedTime(&ms[2], ev[3], ev[4]) != hipSuccess) { ms[2] = 0.0f; (void)hipGetLastError(); }
+    if ((rec & 0xCu) == 0xCu && hipEventElapsedTime(&ms[1], ev[2], ev[3]) != hipSuccess) { ms[1] = 0.0f; (void)hipGetLastError(); }
+    if ((rec & 0x18u) == 0x18u && hipEventElapsedTime(&ms[2], ev[3], ev[4]) != hipSuccess) { ms[2] = 0.0f; (void)hipGetLastError(); }
     return LDPC_OK;
 }
 

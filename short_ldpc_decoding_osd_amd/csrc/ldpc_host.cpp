@@ -362,7 +362,7 @@ int ldpc_gf2elim_host(int32_t *M, int32_t m, int32_t n, int32_t *swaps, int32_t 
     if (!M || m <= 0 || n <= 0) return fail(LDPC_E_ARG, "ldpc_gf2elim_host: bad arguments");
     std::vector<int32_t> sw;
     int rows = gf2elim(M, m, n, &sw);
-    if (swaps) memcpy(swaps, sw.data(), sizeof(int32_t) * sw.size());
+    if (swaps && !sw.empty()) memcpy(swaps, sw.data(), sizeof(int32_t) * sw.size());   // (an empty vector has a null data(): UB for memcpy -- found by the sanitizer build)
     if (nswaps) *nswaps = (int32_t)(sw.size() / 2);
     if (rows_out) *rows_out = rows;
     return LDPC_OK;

@@ -63,6 +63,7 @@ struct ldpc_ctx {
     bool hosd_ok = false;
     void *osd_state = nullptr;     // ldpc::OsdState (TEP tables; per-stream workspaces behind its mutex)
     hipEvent_t *timing = nullptr;  // [LDPC_TIMING_SLOTS][6] events of ldpc_pipeline_run, created with the context
+    unsigned timing_recorded[LDPC_TIMING_SLOTS] = {};   // bit i: event i of the slot was recorded by the last run that used it
 };
 
 namespace ldpc {
@@ -80,7 +81,8 @@ int launch_nms(ldpc_ctx *ctx, const float *d_llr, int64_t B, int T, const float 
 int probe_dpp(bool *ror_up, int *wave_rol_dir);
 int osd_search_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
                        const uint8_t *d_perm, const uint64_t *d_parity, const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric,
-                       int32_t *d_best, int32_t *d_ntep, const uint64_t *d_label, int64_t *d_counts, hipStream_t s);
+                       int32_t *d_best, int32_t *d_ntep, const uint64_t *d_label, int64_t *d_counts, hipStream_t s,
+                       bool *counted_by_search = nullptr);
 int eval_and_compact(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_label, const uint8_t *d_fail, int64_t B,
                      int64_t *d_counts, int32_t *d_index, int32_t *d_count, hipStream_t st);
 

@@ -991,8 +991,9 @@ namespace ldpc {
 // ldpc_osd_search + ldpc_osd_counts for ldpc_pipeline_run: one launch where the search kernel can count itself
 int osd_search_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
                        const uint8_t *d_perm, const uint64_t *d_parity, const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric,
-                       int32_t *d_best, int32_t *d_ntep, const uint64_t *d_label, int64_t *d_counts, hipStream_t s)
+                       int32_t *d_best, int32_t *d_ntep, const uint64_t *d_label, int64_t *d_counts, hipStream_t s, bool *counted_by_search)
 {
+    if (counted_by_search) *counted_by_search = false;
     if (!ctx || !p || F < 0 || (F > 0 && (!d_y || !d_cw || !d_perm || !d_parity)))
         return fail(LDPC_E_ARG, "ldpc_osd_search: bad arguments");
     int rc = check_params(ctx, p, "ldpc_osd_search");
@@ -1002,6 +1003,7 @@ int osd_search_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, 
     bool fused = false;
     rc = launch_search(ctx, d_y, d_index, d_count, F, d_perm, reinterpret_cast<const u64 *>(d_parity), p, d_cw, d_metric, d_best, d_ntep,
                        s, d_label, d_counts, &fused);
+    if (counted_by_search) { *counted_by_search = fused; return rc; }     // (the caller places the counting launch itself)
     if (rc || fused || !d_label || !d_counts) return rc;
     return ldpc_osd_counts(ctx, d_cw, d_label, d_index, d_count, d_ntep, F, d_counts, s);
 }

@@ -840,25 +840,33 @@ __device__ __forceinline__ int pbw_scan_chunk(PbWaveLds<CAP> &L, const PbParams 
         return D;
     };
     u64 kq[PER];
-    unsigned npneed = 0, npmask = 0;
+    unsigned npneed = 0, npmask = 0, survmask = 0;
     int sumdel = 0, neg = 0, nsurv = 0;
     unsigned short *const slist = reinterpret_cast<unsigned short *>(L.list);     // keys the cost bound could not rule out
+    // (branch-free first: the keys, their P' rows and the bound's table entries are read side by side for all of the lane's
+    //  keys -- three LDS round trips per chunk instead of three per key)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int i = lane + 64 * k; kq[k] = i < n ? L.keys[i] : ~0ull; }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int i = lane + 64 * k;
-        kq[k] = ~0ull;
-        if (k * 64 < n) {
-            if (i < n) kq[k] = L.keys[i];
-            const PbTep t = pbw_tep((unsigned)kq[k]);
-            const float rs = __uint_as_float((unsigned)(kq[k] >> 32));      // (an empty slot: NaN, every test below is false)
-            const bool surv = i < n && pbw_cost_floor<CAP>(L, rs, parity(t)) < best0;
+        const PbTep t = pbw_tep((unsigned)kq[k]);
+        const float rs = __uint_as_float((unsigned)(kq[k] >> 32));      // (an empty slot: NaN, every test below is false)
+        const bool surv = i < n && pbw_cost_floor<CAP>(L, rs, parity(t)) < best0;
+        survmask |= surv ? 1u << k : 0u;
+        npneed |= rs > r_safe ? 1u << k : 0u;
+        const int dl = i < n ? pb_delta(t, P.order) : 0;
+        sumdel += dl; neg += dl < 0;
+    }
+    if (__ballot(survmask != 0)) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const bool surv = (survmask >> k) & 1u;
             const u64 sm = __ballot(surv);
             if (sm) {
-                if (surv) slist[nsurv + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] = (unsigned short)i;
+                if (surv) slist[nsurv + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] = (unsigned short)(lane + 64 * k);
                 nsurv += __popcll(sm);
             }
-            npneed |= rs > r_safe ? 1u << k : 0u;
-            if (i < n) { const int dl = pb_delta(t, P.order); sumdel += dl; neg += dl < 0; }
         }
     }
     const int negtot = wave_add_i32(neg), deltot = wave_add_i32(sumdel);
@@ -2238,8 +2246,11 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     PbParams pp;
     pp.order = p->order; pp.nmax = (int)nmax; pp.cmin_off = spill_slots;
     pp.t3 = 3072; pp.budget = 4096;
-    if (const char *e = getenv("LDPC_PB_BUDGET")) pp.budget = atoi(e);   // (tuning aid)
-    pp.t1 = 320; pp.t2 = kPbWaveCap * 13 / 16;   // chunk targets: the first chunk's count is only guessed (+-40 %), the others follow the growth of the counts
+    pp.t1 = 320; pp.t2 = kPbWaveCap * 13 / 16;
+    if (const char *e = getenv("LDPC_PB_BUDGET")) pp.budget = atoi(e);   // (tuning aids)
+    if (const char *e = getenv("LDPC_PB_T2")) pp.t2 = atoi(e);
+    if (const char *e = getenv("LDPC_PB_T1")) pp.t1 = atoi(e);
+   // chunk targets: the first chunk's count is only guessed (+-40 %), the others follow the growth of the counts
     pp.c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)p->snr_db / 10.0)));    // -4 * noise_variance, pb_testing.py:50-52
     const int mode = (p->reserved & 4) ? 2 : ((p->reserved & 2) ? 1 : 0);
     PbOut O{reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep, reinterpret_cast<int *>(p->d_aux)};

@@ -94,3 +94,68 @@ def test_capture_after_reserve_stream(dec):
     for k in ("index", "cw", "metric", "hard"):
         assert np.array_equal(got[k], want[k]), k
     assert np.array_equal(got["counters"], 2 * want["counters"])
+
+
+def test_pb_capture_after_reserve_stream_and_workspace_rules(dec):
+    """ldpc_osd_reserve_stream with the search parameters sizes the PB-OSD workspace too: the FIRST PB-OSD call on the
+    stream may be the captured one.  A workspace a captured graph references can no longer grow
+    (the graph holds its addresses: ADVICE r02) until ldpc_osd_release_stream frees it."""
+    from short_ldpc_decoding_osd_amd import _lib
+    from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline
+    B = 5000
+    y, cw = np_oracle.make_frames(dec.code.G, 2.5, B, np.random.default_rng(88))
+    pipe = BatchPipeline(dec, B, 10, ALPHA0, osd_order=3, osd_algo=_lib.OSD_PB, snr_db=2.5, keep_front=False)
+    pipe.bind(to_dev(y, dec), to_dev(pack_np(cw).view(np.int64), dec))
+    pipe.reset_counters()
+    pipe.run()
+    torch.cuda.synchronize()
+    want = _snapshot(pipe)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        dec.osd_reserve_stream(B, pipe._p.osd)          # no eager PB-OSD call on this stream before the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        pipe.run()
+    pipe.reset_counters()
+    graph.replay()
+    graph.replay()
+    torch.cuda.synchronize()
+    got = _snapshot(pipe)
+    for k in ("index", "cw", "metric", "hard"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["counters"], 2 * want["counters"])
+    # growing the captured stream's workspace is refused ...
+    big = BatchPipeline(dec, 4 * B, 10, ALPHA0, osd_order=3, osd_algo=_lib.OSD_PB, snr_db=2.5, keep_front=False)
+    y2, cw2 = np_oracle.make_frames(dec.code.G, 2.5, 4 * B, np.random.default_rng(89))
+    big.bind(to_dev(y2, dec), to_dev(pack_np(cw2).view(np.int64), dec))
+    with torch.cuda.stream(side):
+        with pytest.raises(_lib.LdpcError, match="captured graph"):
+            big.run()
+    torch.cuda.synchronize()
+    # ... until the graph is gone and the stream's workspace is released
+    del graph
+    dec.osd_release_stream(side)
+    with torch.cuda.stream(side):
+        big.reset_counters()
+        big.run()
+    torch.cuda.synchronize()
+    assert int(big.counters().cpu()[0]) == 4 * B
+
+
+def test_index_bound_debug_aid(dec):
+    """ldpc_osd_params.y_frames: out-of-range entries of a caller-made frame list are replaced by frame 0 and counted
+    instead of being read out of bounds (off by default)."""
+    rng = np.random.default_rng(3)
+    y, cw = np_oracle.make_frames(dec.code.G, 2.5, 64, rng)
+    yd = to_dev(y, dec)
+    idx = np.array([5, 63, 64, 7, -1, 1000000, 0], dtype=np.int32)
+    before = dec.osd_index_errors()
+    out = dec.osd_decode(yd, 1, index=to_dev(idx, dec), params=dec.osd_params(1, y_frames=64))
+    torch.cuda.synchronize()
+    assert dec.osd_index_errors() - before == 3
+    safe = np.where((idx < 0) | (idx >= 64), 0, idx)
+    ref = dec.osd_decode(yd, 1, index=to_dev(safe.astype(np.int32), dec))
+    torch.cuda.synchronize()
+    assert np.array_equal(out["cw"].cpu().numpy(), ref["cw"].cpu().numpy())
+    assert np.array_equal(out["metric"].cpu().numpy(), ref["metric"].cpu().numpy())

@@ -137,3 +137,105 @@ def test_shard_range_edges():
     assert torch.equal(allreduce_counters(t.clone()), t)       # not initialised: identity
     with pytest.raises(ValueError):
         allreduce_counters(torch.zeros(3))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the reference's stop rule in the sharded path (sharding.sweep_point): one counter all-reduce per macro-batch
+# ---------------------------------------------------------------------------------------------------------
+def _stop_worker(rank, world, port, total, batch, stop_errors, out):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    from oracle import np_oracle
+    from short_ldpc_decoding_osd_amd.sharding import shard_range, sweep_point
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    code = np_oracle.Code(os.path.join(ROOT, "short_ldpc_decoding_osd_amd", "data", "CCSDS_ldpc_n128_k64.alist"))
+    y, cw = np_oracle.make_frames(code.G, 2.5, total, np.random.default_rng(5))      # the same global batch on every rank
+    lo, hi = shard_range(total, rank, world)
+    pos = [lo]
+
+    def decode_batch(B):
+        s = pos[0]
+        pos[0] += B
+        return torch.tensor(_oracle_counters(y[s:s + B], cw[s:s + B]), dtype=torch.int64)
+
+    max_batches = -(-shard_range(total, 0, world)[1] // batch)
+    red, ran = sweep_point(decode_batch, hi - lo, batch, max_batches, stop_errors, with_osd=True)
+    out.put((rank, ran, red.tolist(), pos[0] - lo))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stop_errors", [0, 12])
+def test_world2_stop_rule(stop_errors):
+    """Both ranks leave an SNR point on the SAME macro-batch, with the totals a single process gets for the frames that were
+    decoded (pb_testing.py:174 / ldpc_128_testing.py:130 in the sharded path)."""
+    import numpy as np
+    from oracle import np_oracle
+    from short_ldpc_decoding_osd_amd.sharding import end_to_end_errors, shard_range
+    total, batch, world = 2401, 300, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stop_worker, args=(r, world, port, total, batch, stop_errors, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, ran0, red0, used0), (_, ran1, red1, used1) = got
+    assert ran0 == ran1 and red0 == red1                     # same macro-batch, same sums on both ranks
+    # single-process replay of exactly the frames the ranks decoded
+    code = np_oracle.Code(os.path.join(ROOT, "short_ldpc_decoding_osd_amd", "data", "CCSDS_ldpc_n128_k64.alist"))
+    y, cw = np_oracle.make_frames(code.G, 2.5, total, np.random.default_rng(5))
+    want = np.zeros(8, dtype=np.int64)
+    for r, used in ((0, used0), (1, used1)):
+        lo, _ = shard_range(total, r, world)
+        want += np.array(_oracle_counters(y[lo:lo + used], cw[lo:lo + used]), dtype=np.int64)
+    assert red0 == want.tolist()
+    if stop_errors:
+        assert end_to_end_errors(red0, True) >= stop_errors and red0[0] < total     # stopped early ...
+        # ... and not a macro-batch too late: one macro-batch less would have been below the threshold
+        less = np.zeros(8, dtype=np.int64)
+        for r, used in ((0, used0), (1, used1)):
+            lo, _ = shard_range(total, r, world)
+            u = max(used - batch, 0)
+            less += np.array(_oracle_counters(y[lo:lo + u], cw[lo:lo + u]), dtype=np.int64) if u else 0
+        assert end_to_end_errors(less.tolist(), True) < stop_errors
+    else:
+        assert red0[0] == total
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bench.py's own rank launcher (no GPU call in the parent; dummy workers)
+# ---------------------------------------------------------------------------------------------------------
+def _run_spawn(worker_code, timeout=20.0):
+    import subprocess
+    script = (
+        "import sys, types; sys.path.insert(0, %r); import bench\n"
+        "args = types.SimpleNamespace(gpus=3, rank_timeout=%r)\n"
+        "bench.spawn_ranks(args, [], worker=[sys.executable, '-c', %r], have=3, poll=0.05)\n" % (ROOT, timeout, worker_code))
+    return subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=120)
+
+
+def test_spawn_ranks_relays_rank0_line():
+    p = _run_spawn("import os, json; r = int(os.environ['RANK']); assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'; "
+                   "print(json.dumps({'rank': r})) if r == 0 else None")
+    assert p.returncode == 0 and p.stdout.strip() == '{"rank": 0}', (p.stdout, p.stderr)
+
+
+def test_spawn_ranks_kills_the_others_when_one_rank_dies():
+    """Rank 2 dies; ranks 0 and 1 would wait for ever (a barrier nobody completes): the launcher must notice, kill them and fail."""
+    import time
+    t0 = time.monotonic()
+    p = _run_spawn("import os, sys, time; r = int(os.environ['RANK']); sys.exit(7) if r == 2 else time.sleep(600)")
+    assert p.returncode != 0 and "rank 2 exited with code 7" in p.stderr and not p.stdout.strip()
+    assert time.monotonic() - t0 < 60
+
+
+def test_spawn_ranks_overall_timeout():
+    p = _run_spawn("import time; time.sleep(600)", timeout=1.0)
+    assert p.returncode != 0 and "still running" in p.stderr and not p.stdout.strip()
