@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--skip-launches", type=int, default=2, help="warm-up launches of every kernel left out of the mean")
     args = ap.parse_args()
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for d in sorted(glob.glob(args.prefix + "_*")):
+    for d in [args.prefix + "_" + tag for tag in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2")]:   # (exact names: another workload's tag may extend this one)
         if not os.path.isdir(d):
             continue
         for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):

@@ -81,6 +81,7 @@ struct PbParams {
     int order, nmax;
     int t1, t2;                  // chunk targets: first chunk / later chunks
     int t3, budget;              // chunk target of the latency-shaped kernel; TEPs after which a frame may be handed to it
+    int handoff_maxlen;          // ... if its sub-list of list A holds fewer frames than this (many searches: throughput counts, none leaves)
     float c4;
     long long cmin_off;          // offset of the spilled chunk minima inside a wave's global area
 };
@@ -1365,7 +1366,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
             }
             lo = T;
             done += n;
-            if (state == 0 && done >= P.budget && !asked && done < nall) {
+            if (state == 0 && done >= P.budget && !asked && done < nall && len < P.handoff_maxlen) {
                 // a long search: the latency-shaped kernel takes it over if it still has room (at most kPbHeavyCap frames a call)
                 asked = true;
                 int slot = 0;
@@ -2247,6 +2248,12 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     pp.order = p->order; pp.nmax = (int)nmax; pp.cmin_off = spill_slots;
     pp.t3 = 3072; pp.budget = 4096;
     pp.t1 = 320; pp.t2 = kPbWaveCap * 13 / 16;
+    // hand long searches on only when few frames search at all (each of the 16 sub-lists of list A shorter than 1024: from
+    // ~2.25 dB up).  Measured, PB kernels per 131 072-frame step with / without the hand-over: 3.5 dB 0.36 / 0.50 ms, 3.0 dB
+    // 0.49 / 0.81, 2.5 dB 0.88 / 1.14 -- 2.0 dB 2.27 / 1.95, 1.5 dB 4.00 / 3.70, 1.0 dB 7.47 / 7.06: with many searches the
+    // chunk kernel's throughput is what counts and the 1024-thread launch only adds its own time.
+    pp.handoff_maxlen = 1024;
+    if (const char *e = getenv("LDPC_PB_HANDOFF_MAXLEN")) pp.handoff_maxlen = atoi(e);
     if (const char *e = getenv("LDPC_PB_BUDGET")) pp.budget = atoi(e);   // (tuning aids)
     if (const char *e = getenv("LDPC_PB_T2")) pp.t2 = atoi(e);
     if (const char *e = getenv("LDPC_PB_T1")) pp.t1 = atoi(e);
