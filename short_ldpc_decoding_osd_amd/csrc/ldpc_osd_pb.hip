@@ -1264,6 +1264,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
     const int sub = blockIdx.x & (kPbSub - 1);
     const int len = ctl[kPbCtlLenA + kPbCtlLine * sub];
     const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);      // TEPs of weight 1..order
+    // TEPs after which a search may leave for the latency-shaped kernel: the fewer frames search, the sooner (a lone wavefront
+    // takes ~30 us per chunk; measured per step at 3.5 / 3.0 dB: 0.25 / 0.43 ms with 512, 0.27 / 0.41 with 1024, 0.36 / 0.49 with 4096)
+    const int budget = len < 128 ? P.budget / 8 : (len < 448 ? P.budget / 4 : P.budget);
     bool have_cdfh = false;
     for (int k = blockIdx.x >> 4; k < len; k += gridDim.x >> 4) {
         if (!have_cdfh) {
@@ -1366,7 +1369,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
             }
             lo = T;
             done += n;
-            if (state == 0 && done >= P.budget && !asked && done < nall && len < P.handoff_maxlen) {
+            if (state == 0 && done >= budget && !asked && done < nall && len < P.handoff_maxlen) {
                 // a long search: the latency-shaped kernel takes it over if it still has room (at most kPbHeavyCap frames a call)
                 asked = true;
                 int slot = 0;
