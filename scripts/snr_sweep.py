@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--cpu-check", action="store_true",
                     help="rank 0: decode a bounded sample of every SNR point with the CPU port too and print fer_vs_cpu")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="--cpu-check: CPU time budget per SNR point")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="decode streams: consecutive batches alternate between them, so the tail of one batch's search kernels "
+                         "(a few long searches on an emptying chip) overlaps the next batch's decoding (scratch is per stream)")
     args = ap.parse_args()
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
@@ -103,26 +106,60 @@ def main():
     lo, hi = shard_range(args.frames, rank, world)
     mine = hi - lo
     gen = torch.Generator(device=dec.device).manual_seed(rank_seed(20241020, rank))
-    # warm-up: workspaces of the stream (OSD front-end results, PB-OSD lists / caches) are allocated on the first call
-    yw, lw = frames_on_device(dec, min(args.batch, mine, 8192) or 1, float(args.snr[0]), torch.Generator(device=dec.device).manual_seed(1))
-    BatchPipeline(dec, yw.shape[0], args.iters, alpha, osd_order=args.order, osd_algo=ALGOS[args.osd], snr_db=float(args.snr[0]),
-                  want_soft=False, keep_front=False).bind(yw, lw).run()
-    if mine >= args.batch:
-        dec.osd_reserve(args.batch)
+    # the next batch's frames are generated on a second stream while the current batch is decoded (one batch ahead)
+    main_stream, gen_stream = torch.cuda.current_stream(), torch.cuda.Stream()
+    dstreams = [main_stream] + [torch.cuda.Stream() for _ in range(1, max(1, args.streams))]
+    # warm-up with a full-size batch on every stream: the library's workspaces (OSD front-end results, PB-OSD lists / tables)
+    # and torch's per-stream memory pools (hipMalloc synchronises) are sized before the first timed point
+    with torch.cuda.stream(gen_stream):
+        yw, lw = frames_on_device(dec, min(args.batch, max(mine, 1)), float(args.snr[0]), torch.Generator(device=dec.device).manual_seed(1))
+    torch.cuda.synchronize()
+    for st in dstreams:
+        with torch.cuda.stream(st):
+            if args.order is not None:
+                dec.osd_reserve_stream(min(args.batch, max(mine, 1)), dec.osd_params(args.order, ALGOS[args.osd], snr_db=float(args.snr[0])))
+            BatchPipeline(dec, yw.shape[0], args.iters, alpha, osd_order=args.order, osd_algo=ALGOS[args.osd], snr_db=float(args.snr[0]),
+                          want_soft=False, keep_front=False).bind(yw, lw).run()
     torch.cuda.synchronize()
     with_osd = args.order is not None
     max_batches = -(-shard_range(args.frames, 0, world)[1] // args.batch)       # rank 0 owns the largest shard
+
+    def produce(B, snr, st):
+        with torch.cuda.stream(gen_stream):          # (no wait on the decode streams: the generator depends on nothing there)
+            y, lab = frames_on_device(dec, B, snr, gen)
+            ev = torch.cuda.Event()
+            ev.record(gen_stream)
+        for t in (y, lab):
+            t.record_stream(st)                      # (allocated on gen_stream, consumed on a decode stream)
+        return y, lab, ev
+
     for snr in np.linspace(float(args.snr[0]), float(args.snr[1]), int(args.snr[2])):
         snr = round(float(snr), 2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        sizes = [min(args.batch, mine - k * args.batch) for k in range(max_batches) if mine - k * args.batch > 0]
+        ahead = [produce(sizes[0], snr, dstreams[0])] if sizes else []
+        taken = [0]
 
         def decode_batch(B, snr=snr):
-            y, lab = frames_on_device(dec, B, snr, gen)
-            pipe = BatchPipeline(dec, B, args.iters, alpha, osd_order=args.order, osd_algo=ALGOS[args.osd], snr_db=snr,
-                                 want_soft=False, keep_front=False).bind(y, lab)
-            pipe.run()
-            return pipe.counters()
+            y, lab, ev = ahead.pop(0)
+            st = dstreams[taken[0] % len(dstreams)]
+            taken[0] += 1
+            if taken[0] < len(sizes):
+                ahead.append(produce(sizes[taken[0]], snr, dstreams[taken[0] % len(dstreams)]))
+            assert y.shape[0] == B
+            with torch.cuda.stream(st):
+                st.wait_event(ev)
+                pipe = BatchPipeline(dec, B, args.iters, alpha, osd_order=args.order, osd_algo=ALGOS[args.osd], snr_db=snr,
+                                     want_soft=False, keep_front=False).bind(y, lab)
+                pipe.run()
+                c = pipe.counters()
+                done_ev = torch.cuda.Event()
+                done_ev.record(st)
+            if st is not main_stream:
+                c.record_stream(main_stream)
+                main_stream.wait_event(done_ev)      # (the counters are summed on the main stream; the NEXT batch is already enqueued on the other)
+            return c
 
         total, ran = sweep_point(decode_batch, mine, args.batch, max_batches, args.stop_errors, with_osd)   # the point's exchange step(s)
         torch.cuda.synchronize()
