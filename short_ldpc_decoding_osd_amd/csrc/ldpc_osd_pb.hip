@@ -632,6 +632,7 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, PbWalk &W, float T, i
 {
     unsigned long long plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
+    static_assert((CAP + 64) + (CAP + 64) / 8 >= CAP + 128, "a dense trip may write 127 keys past CAP");
     unsigned *const list = L.list;      // entry: q | owner lane << 5 | first slot << 11
     int tail = 0;
 #pragma unroll
@@ -669,25 +670,31 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, PbWalk &W, float T, i
         unsigned char *const cb = reinterpret_cast<unsigned char *>(&L.cur[q >> 2][l]) + (q & 3);
         const int a = has ? (int)*cb : 1;
         const float sbv = q < 31 ? L.w[i] + L.w[j] : (l <= 62 ? L.w[l] : 0.0f);
+        // up to TWO members of the item per trip (the tail of a walk is a few long items: half the trips); the order of the
+        // keys inside a chunk is irrelevant, so the second members simply follow the first ones
         const int m = a - 1;
-        const float s = sbv + L.w[m], sn = sbv + L.w[m > 0 ? m - 1 : 0];
-        const float nx = m > base + 1 ? sn : pbw_nan();
-        const u64 act = __ballot(has);
+        const float s = sbv + L.w[m], s2 = sbv + L.w[m > 0 ? m - 1 : 0], s3 = sbv + L.w[m > 1 ? m - 2 : 0];
+        const bool two = has && m > base + 1 && s2 <= T;
+        const int mlast = two ? m - 1 : m;
+        const float nx = mlast > base + 1 ? (two ? s3 : s2) : pbw_nan();
+        const u64 act = __ballot(has), act2 = __ballot(two);
         const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, (unsigned)cnt));
+        const int pos2 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act2, (unsigned)(cnt + __popcll(act))));
         const bool again = has && nx <= T;
         const u64 more = __ballot(again);
         const int nt = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(more >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)more, 0u));
         wave_fence();                    // (every lane has read its entry: the slots may be written now)
         if (has) {
             L.keys[pos] = ((u64)__float_as_uint(s) << 32) | (code | ((unsigned)m << sh));
-            *cb = (unsigned char)m;
+            if (two) L.keys[pos2] = ((u64)__float_as_uint(s2) << 32) | (code | ((unsigned)(m - 1) << sh));
+            *cb = (unsigned char)mlast;
             if (again) list[nt] = ent; else list[ent >> 11] = __float_as_uint(nx);
         }
-        cnt += __popcll(act);
+        cnt += __popcll(act) + __popcll(act2);
         head = head + 64 < tail ? head + 64 : tail;
         tail += __popcll(more);
         wave_fence();
-        if (tail > CAP) { cnt = CAP + 1; break; }   // every entry ever listed is one member: more than CAP members, an overflow
+        if (tail > CAP) { cnt = CAP + 1; break; }   // every entry ever listed is at least one member: more than CAP members, an overflow
     }
     PBW_STAMP(kPwDense);
     if (cnt > CAP) return cnt;
