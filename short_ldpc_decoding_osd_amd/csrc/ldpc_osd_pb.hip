@@ -1920,6 +1920,7 @@ __global__ __launch_bounds__(NT, MINW) void pb_heavy_kernel(const float *__restr
     // (list C holds at most kPbHeavyCap frames: one length word, one ticket word)
     const int lenc = ctl[kPbCtlLenC];
     const int nlist = lenc < kPbHeavyCap ? lenc : kPbHeavyCap;
+    if ((int)blockIdx.x >= nlist) return;      // (more workgroups than frames -- or nothing handed on at all: leave before any set-up)
     const int nall = P.order == 2 ? kPbTriples0 : kPbTabSize;
     if (tid < 65) B.cdfH[tid] = cdf_half[tid];
     PbItems<NT> I;
