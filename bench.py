@@ -65,7 +65,7 @@ def parse_args(argv=None):
                     help="time eager ldpc_pipeline_run calls instead of replaying the steps from a captured HIP graph "
                          "(one graph = one rotation over the distinct batches; the eager form pays ~18 us of launch / ctypes "
                          "time per 0.3 ms step)")
-    ap.add_argument("--graph-branches", type=int, default=3,
+    ap.add_argument("--graph-branches", type=int, default=4,
                     help="parallel branches of the captured rotation: the distinct batches are independent, so batch i is captured on "
                          "stream i mod N and the branches join at the end of the graph -- the ~5 us dispatch gap after every kernel "
                          "and the kernel tails of one batch then hide behind the kernels of another (1 = one chain)")

@@ -598,15 +598,22 @@ __device__ __forceinline__ void pbw_cursors_load(const PbWaveLds<CAP> &L, unsign
 template <int CAP>
 __device__ __forceinline__ void pbw_walk_init(PbWaveLds<CAP> &L, PbWalk &W, int order, int lane)
 {
+    // every cursor at 64: an item's next member is its last position 63.  Written out from the item geometry (pbw_item) --
+    // going through the general helper here cost 40 spilled VGPRs of long-lived state: the 32 unrolled items' temporaries
+    // set the kernel's register peak.
     const float *w = L.w;
+    const float wl = w[lane], w63 = w[63];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        const PbwItem it = pbw_item(q, lane);
-        const float sb = q < 31 ? w[it.i] + w[it.j] : (lane <= 62 ? w[lane] : 0.0f);
-        const bool live = it.base < 63 && (q < 31 ? order > 2 : (order > 1 || lane == 63));
-        W.nxt[q] = live ? sb + w[63] : pbw_nan();
-        if ((q & 3) == 3) asm volatile("" ::: "memory");   // (keeps the scheduler from issuing all 64 reads at once: registers)
+    for (int q = 0; q < 31; ++q) {
+        const bool first = lane < 62 - q;
+        const int jj = q + 1 + lane;
+        const float wi = first ? w[q] : w[61 - q];
+        const float wj = first ? w[jj < 63 ? jj : 63] : wl;
+        float v = (lane <= 62 && order > 2) ? (wi + wj) + w63 : pbw_nan();
+        asm volatile("" : "+v"(v) : : "memory");     // (one item at a time: finished before the next one's reads are issued)
+        W.nxt[q] = v;
     }
+    W.nxt[31] = lane <= 62 ? (order > 1 ? wl + w63 : pbw_nan()) : w63;
 #pragma unroll
     for (int k = 0; k < 8; ++k) W.ecur[k] = 0x40404040u;
     pbw_cursors_store<CAP>(L, W.ecur, lane);
@@ -709,6 +716,7 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, PbWalk &W, float T, i
         const float v = __uint_as_float(list[p]);       // (a lane without a pending item reads some slot and drops it)
         W.nxt[q] = pend ? v : W.nxt[q];
         slot0 += __popcll(act);
+        if ((q & 7) == 7) asm volatile("" ::: "memory");   // (eight reads in flight, not thirty-two: registers)
     }
     PBW_STAMP(kPwSweepB);
     return cnt;
@@ -854,17 +862,21 @@ __device__ __forceinline__ int pbw_scan_chunk(PbWaveLds<CAP> &L, const PbParams 
     // (branch-free first: the keys, their P' rows and the bound's table entries are read side by side for all of the lane's
     //  keys -- three LDS round trips per chunk instead of three per key)
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { const int i = lane + 64 * k; kq[k] = i < n ? L.keys[i] : ~0ull; }
+    for (int k0 = 0; k0 < PER; k0 += 4) {      // (four keys at a time: eight side by side cost ~40 spilled registers of walk state)
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int i = lane + 64 * k;
-        const PbTep t = pbw_tep((unsigned)kq[k]);
-        const float rs = __uint_as_float((unsigned)(kq[k] >> 32));      // (an empty slot: NaN, every test below is false)
-        const bool surv = i < n && pbw_cost_floor<CAP>(L, rs, parity(t)) < best0;
-        survmask |= surv ? 1u << k : 0u;
-        npneed |= rs > r_safe ? 1u << k : 0u;
-        const int dl = i < n ? pb_delta(t, P.order) : 0;
-        sumdel += dl; neg += dl < 0;
+        for (int u = 0; u < 4; ++u) { const int i = lane + 64 * (k0 + u); kq[k0 + u] = i < n ? L.keys[i] : ~0ull; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u, i = lane + 64 * k;
+            const PbTep t = pbw_tep((unsigned)kq[k]);
+            const float rs = __uint_as_float((unsigned)(kq[k] >> 32));      // (an empty slot: NaN, every test below is false)
+            const bool surv = i < n && pbw_cost_floor<CAP>(L, rs, parity(t)) < best0;
+            survmask |= surv ? 1u << k : 0u;
+            npneed |= rs > r_safe ? 1u << k : 0u;
+            const int dl = i < n ? pb_delta(t, P.order) : 0;
+            sumdel += dl; neg += dl < 0;
+        }
+        asm volatile("" : "+v"(survmask), "+v"(npneed), "+v"(sumdel), "+v"(neg) : : "memory");
     }
     if (__ballot(survmask != 0)) {
 #pragma unroll
