@@ -833,7 +833,6 @@ __device__ __forceinline__ int pbw_scan_chunk(PbWaveLds<CAP> &L, const PbParams 
 {
     constexpr int PER = CAP / 64;
     if (S.nlive <= 1) return -1;      // (the first chunk: one entry in the frontier, its pops are counted one by one)
-    float *const costs = reinterpret_cast<float *>(L.hist);
     const float best0 = S.best;
     // Rule 1 by probes.  With the best fixed, the rule's left-hand side bs = H[beta] + (A[beta] - H[beta]) w1 falls as the sum
     // rises (w1 = exp(c4 rs) spl falls, beta -- a floor of a float quotient, monotone as computed -- falls, A >= H); the
@@ -1922,7 +1921,6 @@ __global__ __launch_bounds__(NT, MINW) void pb_heavy_kernel(const float *__restr
                                                       const PbCarry *__restrict__ carry, const PbPrep *__restrict__ prep, PbOut O,
                                                       unsigned long long *__restrict__ prof_out)
 {
-    constexpr int W = NT / 64;
     // (dynamic LDS: a hipGraph kernel node with more than 64 KiB of STATIC LDS aborts at replay on ROCm 7.2; the size is
     //  registered once in pb_ctx_init)
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_heavy_lds[];
