@@ -763,7 +763,6 @@ void osd_ctx_release(ldpc_ctx *ctx)
         (void)hipFree(st->d_base2);
         (void)hipFree(st->d_cdf_half);
         (void)hipFree(st->d_index_errors);
-        (void)hipFree(st->d_pb_tab);
         delete st;
     }
     ctx->osd_state = nullptr;

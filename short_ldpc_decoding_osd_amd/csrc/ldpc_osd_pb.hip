@@ -80,7 +80,8 @@ struct __attribute__((aligned(16))) PbLds {
 struct PbParams {
     int order, nmax;
     int t1, t2;                  // chunk targets: first chunk / later chunks
-    int t3, budget;              // chunk target of the latency-shaped kernel; TEPs after which a frame may be handed to it
+    int t3, budget;              // chunk target of the workgroup kernel; TEPs after which a frame may be handed to it
+    int budget_s, budget_m;      // ... when its sub-list is short (< 128 frames) / of medium length (< 448)
     int handoff_maxlen;          // ... if its sub-list of list A holds fewer frames than this (many searches: throughput counts, none leaves)
     float c4;
     long long cmin_off;          // offset of the spilled chunk minima inside a wave's global area
@@ -742,7 +743,8 @@ __device__ __forceinline__ float pb_bound_guess(float n)
 // to the list replay); 0: nothing is left to visit (NaN sums).
 template <int CAP, bool PROF>
 __device__ __forceinline__ int pbw_next_chunk(PbWaveLds<CAP> &L, PbWalk &W, int order, float lo, int done, int nall, int target, int lane,
-                                              float &Tout, float &tprev, float &nprev, int &nwalks, unsigned long long (&pt)[kPwSlots])
+                                              float &Tout, float &tprev, float &nprev, int &nwalks, unsigned long long (&pt)[kPwSlots],
+                                              float Tcap = __builtin_inff())
 {
     const float inf = __builtin_inff();
     const float *w = L.w;
@@ -755,6 +757,7 @@ __device__ __forceinline__ int pbw_next_chunk(PbWaveLds<CAP> &L, PbWalk &W, int 
         if (pe > 1.5f && pe < 20.0f) T = lo * __builtin_amdgcn_exp2f((__builtin_amdgcn_logf(want) - __builtin_amdgcn_logf((float)done)) / pe);
     }
     if (!(T > lo)) T = lo > 0.0f ? lo * 1.05f : w[0];
+    if (T > Tcap) T = Tcap;                  // (a caller that wants the chunks to end at a given bound)
     float tp = lo, np_ = (float)done;        // last point with a known count
     int cnt = 0, c_ok = 0;
     float T_ok = lo;
@@ -795,6 +798,7 @@ __device__ __forceinline__ int pbw_next_chunk(PbWaveLds<CAP> &L, PbWalk &W, int 
             Tn = cnt > 0 ? T * __builtin_amdgcn_exp2f((__builtin_amdgcn_logf(want) - __builtin_amdgcn_logf(tot)) / p) : T * 1.1f;
             if (it >= 6 || !(Tn > Tl) || !(Tn < Th)) Tn = Th < inf ? Tl + (Th - Tl) * 0.5f : T * 1.2f;
         }
+        if (Tn > Tcap) Tn = Tcap;
         if (!(Tn > Tl) || !(Tn < Th)) break;
         T = Tn;
     }
@@ -1256,12 +1260,24 @@ __device__ __forceinline__ int pbw_process_chunk(PbWaveLds<CAP> &L, const PbPara
     return 0;
 }
 
-// search state handed from the chunk kernel to the latency-shaped kernel (sums <= lo are visited)
+// A long search handed from the chunk kernel to the workgroup kernel: ONE record per frame with everything the search needs,
+// so that the receiving workgroup starts after a single wide load (its 1024 threads copy the record into LDS side by side)
+// instead of the chain frame number -> source index -> permutation -> y that the chunk kernel went through:
+//   words [0, 520)      the frame's tables as they stand in PbWaveLds (tail, P, w, tq, cdfA), verbatim
+//   words [520, 1032)   the committed cursors, [8][64]
+//   words [1032, 1096)  the permutation: o1 | o2 << 8 per lane
+//   words [1096, ...)   PbCarry: the search state (sums <= lo are visited) and the frame's scalars
 struct PbCarry {
     float lo, best;
     int j, nlive, cmp, suc1, suc2, bestidx;
     u64 bestD, bestE;
+    PbFrame fr;
+    u64 d0, hm, hp;
+    long long f;
 };
+constexpr int kPbRecPrefix = 520, kPbRecCur = 520, kPbRecPerm = 1032, kPbRecScalars = 1096, kPbRecWords = 1152;
+static_assert(kPbRecScalars * 4 % 8 == 0 && kPbRecScalars * 4 + sizeof(PbCarry) <= kPbRecWords * 4, "record layout");
+static_assert(offsetof(PbWaveLds<kPbWaveCap>, cdfH) == kPbRecPrefix * 4, "the record's first part is the head of PbWaveLds");
 
 // One frame of list A per wavefront, from its first TEP to its stop (or to the end of the table); massive ties go to
 // list B (list replay).  Workgroup b serves sub-list b mod 16, entries b / 16, b / 16 + grid / 16, ...
@@ -1272,7 +1288,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
                                                      const u64 *__restrict__ parity_in, PbParams P,
                                                      const double *__restrict__ cdf_half, int *__restrict__ ctl,
                                                      const int *__restrict__ listA, int *__restrict__ listB, int sub_cap,
-                                                     int *__restrict__ listC, PbCarry *__restrict__ carry,
+                                                     unsigned *__restrict__ carry,
                                                      const PbPrep *__restrict__ prep, PbOut O, unsigned long long *__restrict__ prof_out)
 {
     __shared__ PbWaveLds<CAP> L;
@@ -1284,7 +1300,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
     const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);      // TEPs of weight 1..order
     // TEPs after which a search may leave for the latency-shaped kernel: the fewer frames search, the sooner (a lone wavefront
     // takes ~30 us per chunk; measured per step at 3.5 / 3.0 dB: 0.25 / 0.43 ms with 512, 0.27 / 0.41 with 1024, 0.36 / 0.49 with 4096)
-    const int budget = len < 128 ? P.budget / 8 : (len < 448 ? P.budget / 4 : P.budget);
+    const int budget = len < 128 ? P.budget_s : (len < 448 ? P.budget_m : P.budget);
     bool have_cdfh = false;
     for (int k = blockIdx.x >> 4; k < len; k += gridDim.x >> 4) {
         if (!have_cdfh) {
@@ -1394,12 +1410,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
                 if (lane == 0) slot = atomicAdd(&ctl[kPbCtlLenC], 1);
                 slot = __builtin_amdgcn_readfirstlane(slot);
                 if (slot < kPbHeavyCap) {
+                    unsigned *const rec = carry + (long long)slot * kPbRecWords;
+                    const unsigned *const Lw = reinterpret_cast<const unsigned *>(&L);
+                    for (int k = lane; k < kPbRecPrefix; k += 64) rec[k] = Lw[k];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) rec[kPbRecCur + k * 64 + lane] = W.ecur[k];
+                    rec[kPbRecPerm + lane] = (unsigned)o1 | ((unsigned)o2 << 8);
                     if (lane == 0) {
                         PbCarry c;
                         c.lo = lo; c.best = S.best; c.j = S.j; c.nlive = S.nlive; c.cmp = S.cmp; c.suc1 = S.suc1; c.suc2 = S.suc2;
                         c.bestidx = S.bestidx; c.bestD = S.bestD; c.bestE = S.bestE;
-                        carry[slot] = c;
-                        listC[slot] = (int)f;
+                        c.fr = Fr; c.d0 = d0; c.hm = hm; c.hp = hp; c.f = f;
+                        *reinterpret_cast<PbCarry *>(rec + kPbRecScalars) = c;
                     }
                     state = 3;
                 }
@@ -1435,555 +1457,685 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
 }
 
 // ---------------------------------------------------------------------------------------
-// stage 2b: the LATENCY shape, for the few frames whose search runs long (round 2's stage-B kernel, kept for them).
-// One wavefront takes ~1 ms through a complete scan of 43 744 TEPs; at 2.5 dB one frame in 200 is such a scan and the
-// launch would last as long as they do.  A frame that has passed PbParams::budget TEPs in the chunk kernel is therefore
-// handed on -- with its search state, if fewer than kPbHeavyCap frames were before it -- to this kernel: 1024 threads
-// per frame, chunks of ~3072 TEPs generated by binary searches over 2080 items (PbItems), bucket sort, prefix scans
-// across 16 wavefronts: ~23 us per chunk, a complete scan in ~0.3 ms.  When MANY frames run long (1.0 dB) only the first
-// kPbHeavyCap leave; the others stay where throughput is better.
+// stage 2c: long searches, ONE WORKGROUP OF NW WAVEFRONTS PER FRAME (round 3).  The chunk pass above needs no sort, so a
+// chunk is embarrassingly parallel over its keys, and the walk is parallel over the item rows: wavefront v owns 32 / NW of
+// the 32 rows (dealt so that light and heavy rows pair up), walks them into the workgroup's ONE key buffer (slots reserved by
+// an LDS atomic per trip, so the buffer fills evenly whatever the rows give) and scans every NW-th 64-key slice of it.
+// What the wavefronts exchange per chunk is a handful of numbers (counts, frontier growth, the smallest firing sum,
+// positions) through LDS words and ~7 workgroup barriers; the order of the keys in the buffer depends on the wavefronts'
+// timing, the results do not (the pass takes counts, minima and the candidates ordered by sum, a tie leaves it).  Everything a
+// wavefront decides from the exchanged numbers it decides like the others (same values, same arithmetic), so the barriers
+// line up by construction: no barrier stands inside control flow that depends on a wavefront's own keys.
+// A chunk the sort-free pass cannot settle (a tie against a reference key, > 64 candidates, a frontier that may shrink to
+// one entry) is redone by wavefront 0 alone with the single-wavefront code above (sorted path, sub-chunks of <= 512 keys up
+// to the same bound), then the co-operation resumes.  Frames arrive from pb_wave_kernel with their search state and cursors.
 // ---------------------------------------------------------------------------------------
-#define PB_STAMP(k) do { } while (0)
-enum { kProfSetup = 0, kProfPassA, kProfHist, kProfGather, kProfSort, kProfTie, kProfEval1, kProfEval2, kProfCombine, kProfFill,
-       kProfScatter, kProfFinish, kProfFrames, kProfChunks };
-__device__ __forceinline__ PbTep pb_tep(const uchar4 *__restrict__ tab, int id)
-{
-    const uchar4 t = tab[id];
-    return PbTep{t.x, t.y, t.z, t.w};
-}
+constexpr int kCoopCap = 4096;        // keys of a chunk, all wavefronts together
+constexpr int kCoopMaxCand = 64;
+constexpr int kPbCoopW = 16;          // wavefronts per frame
+constexpr int kPbCoopGrid = 256;      // workgroups (frames are handed out by ticket)
 
-template <int NT, int CAP>
-struct __attribute__((aligned(16))) PbBlockLds {
-    SearchLds s;
-    double cdfA[65], cdfH[65];
-    float q[128];
-    float2 tq[64];
-    u64 gath[CAP];          // the chunk as gathered: (sum bits << 32) | table id; after the sort: the costs (float[CAP])
-    u64 keys[CAP];          // the chunk in visit order
-    int bucket[CAP];        // bucket sort: counts, then cursors
-    float red_f[2][NT / 64];
-    int red_i[2][NT / 64];
-    PbFrame fr;
-    // uniform search state
-    float lo, hi_cur, best;
-    int j, nlive, cmp, suc1, suc2, bestidx;
-    u64 bestD, bestE, d0;
-    // per-chunk scratch
-    int nkeys, bstar, degenerate, fallback, gstop, reason, ones, nev, nnb, lnb, ticket;
-    int sub, subtried, sublen[kPbSub];   // stage A: the sub-list being drained
-    unsigned long long prof[24], prof_last;   // diagnostic build only (LDPC_PB_PROFILE)
+template <int NW>
+struct __attribute__((aligned(16))) PbCoopLds {
+    static constexpr int NI = 32 / NW;                    // item rows per wavefront
+    static constexpr int WCAP = 3 * kCoopCap / NW;        // members one wavefront may emit per chunk: three times the mean
+    static_assert(NI >= 1 && NI <= 4, "a wavefront's cursors are the bytes of one word");
+    PbWaveLds<kPbWaveCap> one;        // the frame's tables (tail, P, w, tq, cdf); the rest of it is wavefront 0's when it works alone
+    u64 keys[kCoopCap];
+    unsigned list[NW][WCAP + 64 * NI];
+    unsigned cur[NW][64];             // tentative cursors: byte j of cur[v][lane] = item j of that lane (coop_item)
+    u64 ck[kCoopMaxCand], rk[kCoopMaxCand];
+    float cc[kCoopMaxCand], rc[kCoopMaxCand];
+    int red[8][NW];
+    int nkeys, ncand, nrec, stop2, tie0, ticket[2];
+    PbwState bs;                      // wavefront 0 -> all, after it worked alone
+    int bstate, bstop, bntep;
+    // What wavefront 0 holds in registers when it leaves for coop_solo_range, parked here and read back afterwards: a value
+    // that is live across the call costs a callee-saved register or a scratch slot on EVERY path through the kernel (the
+    // call alone took the kernel from 119 VGPRs and no scratch to 128 VGPRs and 101 spilled ones, reloaded inside the walk's
+    // loops), a value that is stored before it and loaded after it costs nothing anywhere else.
+    float sv[32 / NW + 1][64];
+    struct {
+        PbFrame fr;
+        u64 d0;
+        float lo, T, tprev, nprev, smax;
+        int done, n, seq, it, tk;
+    } su;
+    PbParams sP;
 };
 
-
-// ---------------------------------------------------------------------------------------
-// Direct enumeration of a sum range.  The positions are sorted by reliability (w[0] >= w[1] >= ...) and float addition is
-// monotone, so with the other positions fixed the sum of a TEP is non-increasing in its LAST position m.  The TEPs are
-// therefore 2080 "items" -- all singles {m}; the pairs {i, m} of one i; the triples {i, j, m} of one (i, j) -- inside each
-// of which the members with lo < sum <= T are a contiguous run [a, e) of m, found by a 7-step binary search in LDS.
-// A thread owns 3 (1024 threads) or 9 (256 threads) items; counting a range is one search per item and a block scan, a
-// chunk is written from the runs.  The cost follows the items and the chunk, not the 43 744-entry table, nothing is read
-// from global memory, and the upper bound of a chunk can be ANY value -- the search is exact for every choice -- which
-// pb_pick_bound uses to size the chunks.
-//   item 0: singles;  items 1..63: pairs of i = item - 1;  items 64..2079: triples of the pair tab[item]
-// (a wavefront-wide visit per item with lane = m was measured too: 30 instructions per item at ~6 % useful lanes for the
-//  early chunks, 4-10x the time of the searches; a 1024-bin histogram of all sums costs as much as the table pass it
-//  replaced)
-// ---------------------------------------------------------------------------------------
-template <int NT>
-struct PbItems {
-    static constexpr int IPT = (kPbTriples0 + NT - 1) / NT;
-    // frame-independent (set once per workgroup), packed: bits 0-6 base + 1 (the last position runs over (base, 63];
-    // singles: base = -1, an empty item: 63), bits 7-13 first fixed position + 1 (0: none), bit 14 triple item,
-    // bits 16-31 idb (table id of member m = idb + m; singles: 63 - m)
-    unsigned st[IPT];
-    // per frame
-    float sb[IPT];    // sum of the fixed positions
-    unsigned ea[IPT]; // e | a << 8: members already visited (sum <= lo) [e, 64); members of the chunk being sized [a, e)
-    __device__ __forceinline__ int base(int q) const { return (int)(st[q] & 127u) - 1; }
-    __device__ __forceinline__ int e(int q) const { return (int)(ea[q] & 255u); }
-    __device__ __forceinline__ int a(int q) const { return (int)(ea[q] >> 8); }
+// in-kernel stamps of the diagnostic instantiation (thread 0 of the workgroup), as PBW_STAMP above
+enum { kPcSetup = 0, kPcWalk, kPcScan, kPcSolo, kPcOut, kPcFrames, kPcChunks, kPcSolos, kPcSoloKeys, kPcKeys,
+       kPcWalks, kPcTrips, kPcWList, kPcWDense, kPcWCollect, kPcWBarrier, kPcWPick, kPcSProbe, kPcSKeys, kPcSBar1, kPcSSurv, kPcSBar2, kPcSCand, kPcSMin, kPcSPos, kPcSlots };
+struct PbcProf {
+    unsigned long long pc[kPcSlots], last;
 };
+#define PBC_STAMP(k) do { if constexpr (PROF) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); Q.pc[k] += now__ - Q.last; Q.last = now__; } } while (0)
 
-// first m in [lo, hi) with sb + w[m] <= T (hi if none), for three items of the thread at once: the seven LDS reads of an
-// item depend on each other, those of different items do not
-template <int NT, int G>
-__device__ __forceinline__ void pb_first_le3(const PbItems<NT> &I, const float *w, float T, int (&lo)[PbItems<NT>::IPT], int (&hi)[PbItems<NT>::IPT])
+template <int NW>
+struct CoopRed {
+    int (*buf)[NW];
+    int seq, wave, lane;
+};
+// sum / minimum of one int per wavefront, the same value in every lane of every wavefront (one barrier; eight rotating slots:
+// a slot is rewritten seven barriers after its last reader)
+template <int NW>
+__device__ __forceinline__ int coop_sum(CoopRed<NW> &R, int x)
 {
-    constexpr int Q0 = 3 * G, Q1 = Q0 + 3 < PbItems<NT>::IPT ? Q0 + 3 : PbItems<NT>::IPT;
-#pragma unroll
-    for (int it = 0; it < 7; ++it)
-#pragma unroll
-        for (int q = Q0; q < Q1; ++q) {
-            const int mid = (lo[q] + hi[q]) >> 1;
-            const bool act = lo[q] < hi[q], ok = I.sb[q] + w[mid < 63 ? mid : 63] <= T;
-            hi[q] = (act && ok) ? mid : hi[q];
-            lo[q] = (act && !ok) ? mid + 1 : lo[q];
-        }
-}
-
-// The items are laid out by DESCENDING first position, so those that can hold a member with sum <= T -- their smallest
-// sum, (w_i + w_62) + w_63 for the triples of i, is monotone in i -- are a prefix of the item list; a thread's item
-// slots q >= the returned count hold no such item for any thread (uniform), and are skipped as a whole.
-template <int NT>
-__device__ __forceinline__ int pb_items_slots(const float *w, float T, int order, int lane)
-{
-    const u64 ok = __ballot((w[lane] + w[62]) + w[63] <= T);          // first positions i whose triples can reach below T
-    const int imin = ok ? (int)__builtin_ctzll(ok) : 64;
-    const int r = 64 - imin;                                          // positions >= imin
-    const int items = order > 2 ? kPbPairs0 + r * (r - 1) / 2 : kPbPairs0;
-    const int slots = (items + NT - 1) / NT;
-    return slots < PbItems<NT>::IPT ? slots : PbItems<NT>::IPT;
-}
-
-template <int NT>
-__device__ __forceinline__ void pb_first_le(const PbItems<NT> &I, const float *w, float T, int slots, int (&lo)[PbItems<NT>::IPT], int (&hi)[PbItems<NT>::IPT])
-{
-    pb_first_le3<NT, 0>(I, w, T, lo, hi);
-    if constexpr (PbItems<NT>::IPT > 3) { if (slots > 3) pb_first_le3<NT, 1>(I, w, T, lo, hi); }
-    if constexpr (PbItems<NT>::IPT > 6) { if (slots > 6) pb_first_le3<NT, 2>(I, w, T, lo, hi); }
-    static_assert(PbItems<NT>::IPT <= 9, "item groups");
-}
-
-template <int NT>
-__device__ __forceinline__ void pb_items_static(PbItems<NT> &I, const uchar4 *__restrict__ tab, int order, int tid)
-{
-    const int nitems = order > 2 ? kPbTriples0 : (order > 1 ? kPbPairs0 : 1);
-#pragma unroll
-    for (int q = 0; q < PbItems<NT>::IPT; ++q) {
-        const int it = tid + q * NT;
-        I.st[q] = 64u;                                              // (an empty item: base = 63)
-        if (it == 0) I.st[q] = 0u;
-        else if (it < kPbPairs0 && it < nitems) {
-            const int i = it - 1, m = 63 - i;
-            I.st[q] = (unsigned)(i + 1) | ((unsigned)(i + 1) << 7) | ((unsigned)(kPbPairs0 + m * (m - 1) / 2 - (i + 1)) << 16);
-        } else if (it < nitems) {
-            const uchar4 t = tab[it];
-            const int i = t.x, j = t.y, m = 63 - i, r = 64 - j;
-            I.st[q] = (unsigned)(j + 1) | ((unsigned)(i + 1) << 7) | (1u << 14) |
-                      ((unsigned)(kPbTriples0 + m * (m - 1) * (m - 2) / 6 + m * (m - 1) / 2 - r * (r - 1) / 2 - (j + 1)) << 16);
-        }
-    }
-}
-
-// per-frame part: fixed sums, and the members with sum <= lo (already visited) cut off
-template <int NT>
-__device__ __forceinline__ void pb_items_frame(PbItems<NT> &I, const float *w, float lo)
-{
-    constexpr int IPT = PbItems<NT>::IPT;
-    int l[IPT], h[IPT];
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) {
-        const int i1 = (int)((I.st[q] >> 7) & 127u);     // first fixed position + 1
-        float sb = i1 ? w[i1 - 1] : 0.0f;
-        if (I.st[q] & (1u << 14)) sb = sb + w[I.base(q)];
-        I.sb[q] = sb;
-        l[q] = I.base(q) + 1; h[q] = 64;
-    }
-    if (!(lo < 0.0f)) pb_first_le(I, w, lo, IPT, l, h);
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) { const int e = lo < 0.0f ? 64 : l[q]; I.ea[q] = (unsigned)e | ((unsigned)e << 8); }
-}
-
-// a := start of the members with sum <= T (never past e); returns this thread's number of members in [a, e)
-template <int NT>
-__device__ __forceinline__ int pb_items_bound(PbItems<NT> &I, const float *w, float T, int order, int lane)
-{
-    constexpr int IPT = PbItems<NT>::IPT;
-    int l[IPT], h[IPT];
-    const int slots = pb_items_slots<NT>(w, T, order, lane);
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) { h[q] = I.e(q); l[q] = q < slots ? I.base(q) + 1 : h[q]; l[q] = l[q] < h[q] ? l[q] : h[q]; }
-    pb_first_le(I, w, T, slots, l, h);
-    int local = 0;
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) { I.ea[q] = (I.ea[q] & 255u) | ((unsigned)l[q] << 8); local += I.e(q) - l[q]; }
-    return local;
-}
-
-// exclusive prefix of `local` over the threads of the workgroup and the total (one barrier; `slot` alternates between
-// successive calls so that a slow reader of the previous call is never overwritten)
-template <int NT, int CAP>
-__device__ __forceinline__ int pb_block_scan(PbBlockLds<NT, CAP> &B, int local, int lane, int wave, int slot, int &total)
-{
-    const int incl = wave_incl_add(local, lane);
-    if (lane == 63) B.red_i[slot][wave] = incl;
+    int *const s = R.buf[R.seq++ & 7];
+    if (R.lane == 0) s[R.wave] = x;
     __syncthreads();
-    int run = incl - local;
-    total = 0;
+    int a = 0;
 #pragma unroll
-    for (int w = 0; w < NT / 64; ++w) { const int v = B.red_i[slot][w]; total += v; run += w < wave ? v : 0; }
-    return run;
+    for (int v = 0; v < NW; ++v) a += s[v];
+    return a;
+}
+template <int NW>
+__device__ __forceinline__ int coop_min(CoopRed<NW> &R, int x)
+{
+    int *const s = R.buf[R.seq++ & 7];
+    if (R.lane == 0) s[R.wave] = x;
+    __syncthreads();
+    int a = s[0];
+#pragma unroll
+    for (int v = 1; v < NW; ++v) a = s[v] < a ? s[v] : a;
+    return a;
 }
 
-// the members [a, e) of my items as chunk keys from slot `run` on; then the range is consumed (e := a)
-template <int NT, int CAP>
-__device__ __forceinline__ void pb_items_write(PbBlockLds<NT, CAP> &B, PbItems<NT> &I, const float *w, int run)
+// The 2048 items (row q, lane l) are dealt to the wavefronts by (5 l + 3 q) mod 16: every wavefront holds four items of
+// every row, spread over the lanes, and a chunk's keys come from the sixteen wavefronts within ~10 % of each other
+// (dealing whole rows: the fullest wavefront emits 1.4-1.9 times the mean, the others wait for it at every exchange).
+// Item j (0, 1) of lane `lane` in wavefront v:
+template <int NW>
+__device__ __forceinline__ void coop_item(int v, int j, int lane, int &q, int &l)
+{
+    static_assert(NW == 16, "the dealing is written for sixteen wavefronts");
+    q = 16 * j + (lane >> 2);
+    l = ((13 * (v - 3 * q)) & 15) + 16 * (lane & 3);        // 5 l = v - 3 q (mod 16), 5 * 13 = 1
+}
+
+__device__ __forceinline__ PbwItem pbw_item_rt(int q, int l)
+{
+    PbwItem it;
+    const bool tri = q < 31, first = l < 62 - q;
+    it.i = tri ? (first ? q : 61 - q) : l;
+    it.j = tri ? (first ? q + 1 + l : l) : l;
+    it.base = tri ? (l <= 62 ? it.j : 63) : (l <= 62 ? l : -1);
+    it.code = tri ? ((3u << 24) | ((unsigned)it.j << 8) | (unsigned)it.i) : (l <= 62 ? ((2u << 24) | (unsigned)l) : (1u << 24));
+    it.sh = tri ? 16 : (l <= 62 ? 8 : 0);
+    return it;
+}
+// sum of the next member of item (q, l) whose cursor is a (members [a, 64) are visited); NaN: none left
+__device__ __forceinline__ float pbw_next_sum(const float *w, int q, int l, int a, int order)
+{
+    const PbwItem it = pbw_item_rt(q, l);
+    const bool live = a > it.base + 1 && (q < 31 ? order > 2 : (order > 1 || l == 63));
+    const float sb = q < 31 ? w[it.i] + w[it.j] : (l <= 62 ? w[l] : 0.0f);
+    const float s = sb + w[a > 0 ? a - 1 : 0];
+    return live ? s : pbw_nan();
+}
+
+template <int NW>
+__device__ __forceinline__ void coop_refresh(float (&nxt)[32 / NW], unsigned cur, const float *w, int order, int lane, int wave)
 {
 #pragma unroll
-    for (int q = 0; q < PbItems<NT>::IPT; ++q) {
-        const int a = I.a(q), e = I.e(q), idb = (int)(I.st[q] >> 16);
-        const bool singles = (I.st[q] & 127u) == 0u;
-        for (int m = a; m < e; ++m)
-            B.gath[run++] = ((u64)__float_as_uint(I.sb[q] + w[m]) << 32) | (unsigned)(singles ? 63 - m : idb + m);
-        I.ea[q] = (unsigned)a | ((unsigned)a << 8);
+    for (int j = 0; j < 32 / NW; ++j) {
+        int q, l;
+        coop_item<NW>(wave, j, lane, q, l);
+        nxt[j] = pbw_next_sum(w, q, l, (int)((cur >> (8 * j)) & 255u), order);
     }
 }
 
+// pbw_walk (see there: list / dense / collect) over one wavefront's rows, the keys into the workgroup's buffer.
+// cnt = members this wavefront emitted since the chunk began; returns the new count, -1: the buffer (or this wavefront's
+// list) is full -- the walk stopped half way, nxt still describes the cursors it STARTED from.
+template <int NW, bool PROF>
+__device__ __forceinline__ int coop_walk(PbCoopLds<NW> &L, float (&nxt)[32 / NW], float T, int cnt, int lane, int wave, PbcProf &Q)
+{
+    constexpr int NI = 32 / NW, WCAP = PbCoopLds<NW>::WCAP;
+    unsigned *const list = L.list[wave];       // entry: j | owner lane << 2 | first slot << 8
+    unsigned *const cur = L.cur[wave];
+    const float *w = L.one.w;
+    int tail = 0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const bool pend = nxt[j] <= T;
+        const u64 act = __ballot(pend);
+        if (act) {
+            const int p = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+            if (pend) list[p] = (unsigned)j | ((unsigned)lane << 2) | ((unsigned)p << 8);
+            tail += __popcll(act);
+        }
+    }
+    PBC_STAMP(kPcWList);
+    if (tail == 0) return cnt;
+    wave_fence();
+    int head = 0;
+    bool over = false;
+    while (head < tail) {
+        if constexpr (PROF) Q.pc[kPcTrips] += 1;
+        const int e = head + lane;
+        const bool has = e < tail;
+        const unsigned ent = has ? list[e] : 0u;
+        const int j = (int)(ent & 3u), ol = (int)((ent >> 2) & 63u);     // the entry's owner
+        int q, l;
+        coop_item<NW>(wave, j, ol, q, l);
+        const PbwItem it = pbw_item_rt(q, l);
+        unsigned char *const cb = reinterpret_cast<unsigned char *>(&cur[ol]) + j;
+        const int a = has ? (int)*cb : 1;
+        const float sbv = q < 31 ? w[it.i] + w[it.j] : (l <= 62 ? w[l] : 0.0f);
+        const int m = a - 1;
+        const float s = sbv + w[m], s2 = sbv + w[m > 0 ? m - 1 : 0], s3 = sbv + w[m > 1 ? m - 2 : 0];
+        const bool two = has && m > it.base + 1 && s2 <= T;
+        const int mlast = two ? m - 1 : m;
+        const float nx = mlast > it.base + 1 ? (two ? s3 : s2) : pbw_nan();
+        const u64 act = __ballot(has), act2 = __ballot(two);
+        const int c1 = __popcll(act), c2 = __popcll(act2);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&L.nkeys, c1 + c2);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + c1 + c2 > kCoopCap || cnt + c1 + c2 > WCAP) { over = true; break; }
+        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+        const int pos2 = base + c1 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act2, 0u));
+        const bool again = has && nx <= T;
+        const u64 more = __ballot(again);
+        const int nt = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(more >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)more, 0u));
+        wave_fence();                    // (every lane has read its entry: the slots may be written now)
+        if (has) {
+            L.keys[pos] = ((u64)__float_as_uint(s) << 32) | (it.code | ((unsigned)m << it.sh));
+            if (two) L.keys[pos2] = ((u64)__float_as_uint(s2) << 32) | (it.code | ((unsigned)(m - 1) << it.sh));
+            *cb = (unsigned char)mlast;
+            if (again) list[nt] = ent; else list[ent >> 8] = __float_as_uint(nx);
+        }
+        cnt += c1 + c2;
+        head = head + 64 < tail ? head + 64 : tail;
+        tail += __popcll(more);          // (<= 64 NI + members emitted <= the list's size)
+        wave_fence();
+    }
+    PBC_STAMP(kPcWDense);
+    if (over) return -1;
+    int slot0 = 0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const bool pend = nxt[j] <= T;
+        const u64 act = __ballot(pend);
+        const int p = slot0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+        const float v = __uint_as_float(list[p]);
+        nxt[j] = pend ? v : nxt[j];
+        slot0 += __popcll(act);
+    }
+    PBC_STAMP(kPcWCollect);
+    return cnt;
+}
 
-// Upper bound T of the next chunk: 0 < #(lo < sum <= T) <= CAP, aimed at `target` members.  First guess from
-// pb_bound_guess (or, past the first chunk, from the growth exponent between the last two bounds), then corrected with the
-// exact counts it meets (secant step on log N over log T), bisected when that stops helping.  Every wavefront runs the
-// same arithmetic on the same values.  Returns the count in n (-1: the range cannot be split -- massively equal sums --
-// and the frame goes to the list replay) and the write offset of this wavefront's share in wbase.
-template <int NT, int CAP>
-__device__ __forceinline__ float pb_pick_bound(PbBlockLds<NT, CAP> &B, PbItems<NT> &I, const float *w, int order, float lo, int done, int nall,
-                                               int target, int lane, int wave, int &n, int &run)
+// pbw_next_chunk for the workgroup: the same T in every wavefront, sized by the SUM of their counts (one barrier per
+// walk).  Returns the chunk's size (keys L.keys[0 .. n), cursors committed to ecur), -1: cannot be split, 0: nothing left.
+template <int NW, bool PROF>
+__device__ __forceinline__ int coop_next_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R, float (&nxt)[32 / NW], unsigned &ecur, int order, float lo, int done,
+                                               int nall, int target, int lane, int wave, float &Tout, float &tprev, float &nprev, PbcProf &Q)
 {
     const float inf = __builtin_inff();
+    const float *w = L.one.w;
     const float m3 = (w[61] + w[62]) + w[63];
     const float want = (float)(done + target);
     float Tl = lo, Th = inf;
-    float T = nall - done <= CAP ? inf : m3 * pb_bound_guess(want);
+    float T = nall - done <= kCoopCap / 2 ? inf : m3 * pb_bound_guess(want);
+    if (tprev > 0.0f && nprev > 0.0f && lo > tprev && (float)done > nprev && T < inf) {
+        const float pe = (__builtin_amdgcn_logf((float)done) - __builtin_amdgcn_logf(nprev)) / (__builtin_amdgcn_logf(lo) - __builtin_amdgcn_logf(tprev));
+        if (pe > 1.5f && pe < 20.0f) T = lo * __builtin_amdgcn_exp2f((__builtin_amdgcn_logf(want) - __builtin_amdgcn_logf((float)done)) / pe);
+    }
     if (!(T > lo)) T = lo > 0.0f ? lo * 1.05f : w[0];
-    float tp = lo, np_ = (float)done;        // last point with a known count (lo > 0 and done > 0: usable for the exponent)
-    for (int it = 0;; ++it) {
-        int c;
-        run = pb_block_scan(B, pb_items_bound(I, w, T, order, lane), lane, wave, it & 1, c);
-        if (c > 0 && c <= CAP && (!(T < inf) || 5 * c >= 2 * target || it >= 2)) { n = c; return T; }
-        if (it >= 40 || !(T < inf)) break;
+    float tp = lo, np_ = (float)done;
+    int cnt = 0, c_ok = 0, tot_ok = 0, r = 0;      // cnt / c_ok: this wavefront's members; tot_ok: the workgroup's
+    bool anyover = false;
+    float T_ok = lo;
+    unsigned a_ok = ecur;
+    for (int it = 0; it < 48; ++it) {
+        PBC_STAMP(kPcWPick);
+        if constexpr (PROF) Q.pc[kPcWalks] += 1;
+        r = coop_walk<NW, PROF>(L, nxt, T, cnt, lane, wave, Q);
+        const int packed = coop_sum<NW>(R, r < 0 ? (1 << 24) : r);
+        PBC_STAMP(kPcWBarrier);
+        anyover = (packed >> 24) != 0;
+        const int tot = packed & 0xFFFFFF;
+        bool over = false;
+        if (anyover) {
+            if (tot_ok > 0) break;
+            over = true;
+            Th = T;
+            L.cur[wave][lane] = ecur;                 // every wavefront back to the committed cursors
+            if (r > 0) coop_refresh<NW>(nxt, ecur, w, order, lane, wave);
+            cnt = 0;
+            if (wave == 0 && lane == 0) L.nkeys = 0;
+            __syncthreads();
+        } else {
+            cnt = r;
+            if (tot > 0 && (!(T < inf) || 5 * tot >= 2 * target || it >= 3)) {
+                c_ok = cnt; tot_ok = tot; T_ok = T;
+                a_ok = L.cur[wave][lane];
+                break;
+            } else if (!(T < inf)) {
+                return 0;
+            } else {
+                if (tot > 0) { c_ok = cnt; tot_ok = tot; T_ok = T; a_ok = L.cur[wave][lane]; }
+                Tl = T;
+            }
+        }
         float Tn;
-        if (c == 0) { Tl = T; Tn = T * 1.1f; }
-        else {
-            if (c > CAP) Th = T;
-            const float tot = (float)(done + c);
+        if (over) {
+            Tn = Tl > 0.0f ? Tl + (Th - Tl) * 0.5f : Th * 0.9f;
+        } else {
+            const float totf = (float)(done + tot);
             float p = 6.0f;
-            if (tp > 0.0f && np_ > 0.0f && tot != np_ && T != tp) {
-                const float pe = (__builtin_amdgcn_logf(tot) - __builtin_amdgcn_logf(np_)) / (__builtin_amdgcn_logf(T) - __builtin_amdgcn_logf(tp));
+            if (tp > 0.0f && np_ > 0.0f && totf != np_ && T != tp) {
+                const float pe = (__builtin_amdgcn_logf(totf) - __builtin_amdgcn_logf(np_)) / (__builtin_amdgcn_logf(T) - __builtin_amdgcn_logf(tp));
                 if (pe > 1.5f && pe < 20.0f) p = pe;
             }
-            tp = T; np_ = tot;
-            Tn = T * __builtin_amdgcn_exp2f((__builtin_amdgcn_logf(want) - __builtin_amdgcn_logf(tot)) / p);
+            if (tot > 0) { tp = T; np_ = totf; }
+            Tn = tot > 0 ? T * __builtin_amdgcn_exp2f((__builtin_amdgcn_logf(want) - __builtin_amdgcn_logf(totf)) / p) : T * 1.1f;
+            if (it >= 6 || !(Tn > Tl) || !(Tn < Th)) Tn = Th < inf ? Tl + (Th - Tl) * 0.5f : T * 1.2f;
         }
-        if (it >= 6 || !(Tn > Tl) || !(Tn < Th)) Tn = Th < inf ? Tl + (Th - Tl) * 0.5f : T * 1.2f;
         if (!(Tn > Tl) || !(Tn < Th)) break;
         T = Tn;
     }
-    n = -1;
-    return lo;
+    if (tot_ok == 0) {
+        // (the last walk overflowed and was rolled back above, or every walk came back empty: the cursors are the committed ones)
+        return -1;
+    }
+    if (anyover) {     // an overflow after a usable shorter chunk: back to that one (keys [0, tot_ok) are intact)
+        wave_fence();
+        L.cur[wave][lane] = a_ok;
+        if (r >= 0 && r != c_ok) coop_refresh<NW>(nxt, a_ok, w, order, lane, wave);
+    }
+    ecur = a_ok;
+    tprev = lo; nprev = (float)done;
+    Tout = T_ok;
+    return tot_ok;
 }
 
-// The n gathered keys of one chunk (all TEPs of a sum range): sort into visit order, evaluate in parallel, apply
-// the sequential rules.  Returns 0 = no rule fired (B.j / B.nlive advanced), 1 = stopped (stop / ntep set),
-// 2 = a run of more than kPbMaxTie equal sums (frame goes to the list replay).
-template <int NT, int CAP, bool PROF>
-__device__ int pb_process_chunk(PbBlockLds<NT, CAP> &B, const uchar4 *__restrict__ tab, const PbParams &P, const PbFrame &Fr,
-                                u64 d0, int n, float mn, float mx, int tid, int &stop, int &ntep)
+// pbw_scan_chunk for the workgroup: wavefront v scans the 64-key slices v, v + NW, ... of the n keys; the reductions go
+// through LDS.  Returns 0 / 1 / -1 like pbw_scan_chunk, the same value in every wavefront; -1 leaves the state untouched.
+template <int NW, bool PROF>
+__device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R, const PbParams &P, const PbFrame &Fr, u64 d0, int n, float mn, float mx,
+                                               int lane, int wave, PbwState &S, int &stop, int &ntep, PbcProf &Q)
 {
-    constexpr int W = NT / 64;
-    SearchLds &L = B.s;
-    const int lane = tid & 63, wave = tid >> 6;
-    u64 *const K = B.gath;                              // the chunk in visit order ends up where it was gathered
-    // ---- bucket sort.  CAP buckets over the chunk's sum range (mn, mx] -- its bounds, known to the caller -- hold ~1 key each (<= ~14 near the dense upper
-    // end): counts -> offsets (scan) -> scatter into B.keys (grouped by bucket) -> every key counts the keys of its own
-    // bucket that sort before it and lands at bucket start + rank in B.gath.  No dependent chains: a bitonic sort of the
-    // same 1024 keys took 55 barrier-separated LDS steps (39 % of the stage-A kernel), an insertion sort inside the
-    // buckets left one thread with ~50 dependent LDS round trips; this is ~8 barriers and independent reads.
+    constexpr int CAP = kPbWaveCap, PER = kCoopCap / (64 * NW);
+    const PbWaveLds<CAP> &T0 = L.one;
+    if (S.nlive <= 1) return -1;
+    const float best0 = S.best;
+    float r_safe;     // rule 1 by probes (pbw_scan_chunk)
     {
-        for (int b = tid; b < CAP; b += NT) B.bucket[b] = 0;
-        if (tid == 0) B.fallback = 0;
-        __syncthreads();
-        PB_STAMP(16);
-        const float scale = mx > mn ? (float)CAP / (mx - mn) : 0.0f;
-        const bool flat = !(scale < 3.0e38f);           // denormally close sums: one bucket
-        for (int i = tid; i < n; i += NT) {
-            const float sv = __uint_as_float((unsigned)(B.gath[i] >> 32));
-            atomicAdd(&B.bucket[flat ? 0 : (int)__builtin_fminf((sv - mn) * scale, (float)(CAP - 1))], 1);
+        const float rp = lane == 63 ? mx : mn + (mx - mn) * ((float)(lane + 1) * (1.0f / 64.0f));
+        float w1;
+        const float bs = pb_promising_bs(rp, best0, Fr, P.c4, T0.cdfA, T0.cdfH, w1);
+        const u64 unsafe = ~__ballot((double)bs > Fr.p_t_pro * 1.001);
+        const int u = unsafe ? __builtin_ctzll(unsafe) : 64;
+        r_safe = u == 0 ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rp), u - 1));
+    }
+    PBC_STAMP(kPcSProbe);
+    const auto parity = [&](const PbTep &t) {
+        u64 D = d0 ^ T0.P[t.p0];
+        if (t.wt > 1) D ^= T0.P[t.p1];
+        if (t.wt > 2) D ^= T0.P[t.p2];
+        return D;
+    };
+    const auto sumbits = [](u64 key) { return (unsigned)(key >> 32); };
+    u64 kq[PER];
+    unsigned npneed = 0, npmask = 0, survmask = 0;
+    int sumdel = 0, neg = 0, nsurv = 0;
+    unsigned short *const slist = reinterpret_cast<unsigned short *>(L.list[wave]);     // (the walk's list is idle now)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int i = (k * NW + wave) * 64 + lane; kq[k] = i < n ? L.keys[i] : ~0ull; }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = (k * NW + wave) * 64 + lane;
+        const PbTep t = pbw_tep((unsigned)kq[k]);
+        const float rs = __uint_as_float((unsigned)(kq[k] >> 32));      // (an empty slot: NaN, every test below is false)
+        const bool surv = i < n && pbw_cost_floor<CAP>(T0, rs, parity(t)) < best0;
+        survmask |= surv ? 1u << k : 0u;
+        npneed |= rs > r_safe ? 1u << k : 0u;
+        const int dl = i < n ? pb_delta(t, P.order) : 0;
+        sumdel += dl; neg += dl < 0;
+    }
+    if (__ballot(survmask != 0)) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const bool surv = (survmask >> k) & 1u;
+            const u64 sm = __ballot(surv);
+            if (sm) {
+                if (surv) slist[nsurv + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] = (unsigned short)((k * NW + wave) * 64 + lane);
+                nsurv += __popcll(sm);
+            }
         }
-        __syncthreads();
-        PB_STAMP(17);
-        constexpr int PERB = CAP / NT;
-        int cnts[PERB], local = 0;
-#pragma unroll
-        for (int q = 0; q < PERB; ++q) { cnts[q] = B.bucket[tid * PERB + q]; local += cnts[q]; if (cnts[q] > 64) B.fallback = 1; }
-        const int incl = wave_incl_add(local, lane);
-        if (lane == 63) B.red_i[0][wave] = incl;
-        __syncthreads();
-        int run = incl - local;
-        for (int w = 0; w < wave; ++w) run += B.red_i[0][w];
-#pragma unroll
-        for (int q = 0; q < PERB; ++q) { B.bucket[tid * PERB + q] = run; run += cnts[q]; }    // start offsets = cursors
-        __syncthreads();
-        PB_STAMP(18);
-        if (!B.fallback) {
-            for (int i = tid; i < n; i += NT) {
-                const u64 key = B.gath[i];
-                const float sv = __uint_as_float((unsigned)(key >> 32));
-                B.keys[atomicAdd(&B.bucket[flat ? 0 : (int)__builtin_fminf((sv - mn) * scale, (float)(CAP - 1))], 1)] = key;
+    }
+    PBC_STAMP(kPcSKeys);
+    if (wave == 0 && lane == 0) { L.ncand = 0; L.nrec = 0; L.stop2 = 0; L.tie0 = 0; }
+    // frontier growth and the pops that shrink it, over the whole chunk, in one exchange (per wavefront: |growth| <= 2 PER 64 < 2^12)
+    const int packed = coop_sum<NW>(R, (wave_add_i32(neg) << 18) + (wave_add_i32(sumdel) + 4096));
+    const int negtot = packed >> 18, deltot = (packed & 0x3FFFF) - NW * 4096;
+    PBC_STAMP(kPcSBar1);
+    if (S.nlive - negtot <= 1) return -1;
+    // the survivors' exact costs; candidates (cost below the chunk-start best) go to the workgroup's list
+    if (nsurv) {
+        wave_fence();
+        for (int b0 = 0; b0 < nsurv; b0 += 64) {
+            const bool has = b0 + lane < nsurv;
+            const u64 key = has ? L.keys[slist[b0 + lane]] : 0ull;
+            const float c = has ? pbw_cost_exact<CAP>(T0, __uint_as_float((unsigned)(key >> 32)), parity(pbw_tep((unsigned)key))) : __builtin_inff();
+            const bool cand = c < best0;
+            const u64 cm = __ballot(cand);
+            if (cm) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&L.ncand, __popcll(cm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+                if (cand && idx < kCoopMaxCand) { L.ck[idx] = key; L.cc[idx] = c; }
             }
-            __syncthreads();   // cursors are now the END offsets of the buckets
-            PB_STAMP(19);
-            for (int i = tid; i < n; i += NT) {
-                const u64 key = B.keys[i];
-                const float sv = __uint_as_float((unsigned)(key >> 32));
-                const int b = flat ? 0 : (int)__builtin_fminf((sv - mn) * scale, (float)(CAP - 1));
-                const int end = B.bucket[b], start = b ? B.bucket[b - 1] : 0;
-                int r = 0;
-                for (int jj = start; jj < end; ++jj) r += B.keys[jj] < key;
-                K[start + r] = key;
+        }
+    }
+    if (__ballot(npneed != 0)) {      // rule 1 for the keys above the last safe probe (the last chunk of a search)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const bool need = (npneed >> k) & 1u;
+            if (__ballot(need)) {
+                float w1;
+                if (need && pb_not_promising(__uint_as_float((unsigned)(kq[k] >> 32)), best0, Fr, P.c4, T0.cdfA, T0.cdfH, w1)) npmask |= 1u << k;
             }
-            __syncthreads();
-            PB_STAMP(20);
-        } else {   // a crowded bucket (massively clustered sums): bitonic sort of the whole chunk in place
-            int npow = 2;
-            while (npow < n) npow <<= 1;
-            for (int i = n + tid; i < npow; i += NT) K[i] = ~0ull;
-            __syncthreads();
-            for (int k = 2; k <= npow; k <<= 1)
-                for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                    for (int i = tid; i < (npow >> 1); i += NT) {
-                        const int a = ((i & ~(jj - 1)) << 1) | (i & (jj - 1)), b = a | jj;
-                        const u64 x = K[a], yv = K[b];
-                        if ((x > yv) == ((a & k) == 0)) { K[a] = yv; K[b] = x; }
+        }
+    }
+    PBC_STAMP(kPcSSurv);
+    __syncthreads();
+    PBC_STAMP(kPcSBar2);
+    const int ncand = L.ncand;
+    if (ncand > kCoopMaxCand) return -1;
+    bool tie = false;
+    if (ncand > 0) {   // (the same in every wavefront) wavefront 0 orders the candidates and finds the records; the others wait
+        if (wave == 0) {
+            const u64 my = lane < ncand ? L.ck[lane] : ~0ull;
+            const float myc = lane < ncand ? L.cc[lane] : 0.0f;
+            int rk0 = 0;
+            bool t0 = false;
+            for (int d = 0; d < ncand; ++d) { const u64 o = L.ck[d]; rk0 += sumbits(o) < sumbits(my); t0 |= lane < ncand && sumbits(o) == sumbits(my) && o != my; }
+            wave_fence();
+            if (lane < ncand) { L.ck[rk0] = my; L.cc[rk0] = myc; }
+            wave_fence();
+            int nrec = 0, stop2 = 0;
+            if (!__ballot(t0)) {
+                float before = best0;
+                for (int t = 0; t < ncand && !stop2; ++t) {
+                    const u64 key = L.ck[t];
+                    const float c = L.cc[t];
+                    if (c < before) {
+                        if (lane == 0) { L.rk[nrec] = key; L.rc[nrec] = c; }
+                        ++nrec;
+                        const float w1 = det_expf(P.c4 * __uint_as_float((unsigned)(key >> 32))) * Fr.spl;
+                        if (pb_success(parity(pbw_tep((unsigned)key)), w1, T0.tq, Fr)) stop2 = 1;
+                        before = c;
                     }
-                    __syncthreads();
                 }
-        }
-        if constexpr (PROF) { if (tid == 0) { B.prof[14] += B.fallback; B.prof[15] += n; } }
-    }
-    PB_STAMP(kProfSort);
-    // ---- equal sums: list order (pb_visit_less); one thread per run of equal sums
-    for (int i = tid; i + 1 < n; i += NT) {
-        const unsigned si = (unsigned)(K[i] >> 32);
-        if ((i == 0 || (unsigned)(K[i - 1] >> 32) != si) && (unsigned)(K[i + 1] >> 32) == si) {
-            int g = 2;
-            while (i + g < n && g <= kPbMaxTie && (unsigned)(K[i + g] >> 32) == si) ++g;
-            if (g > kPbMaxTie) { B.degenerate = 1; continue; }
-            for (int a = 1; a < g; ++a) {
-                const u64 ka = K[i + a];
-                const PbTep ta = pb_tep(tab, (int)(unsigned)ka);
-                int b = a;
-                while (b > 0 && pb_visit_less(L.w, ta, pb_tep(tab, (int)(unsigned)K[i + b - 1]))) { K[i + b] = K[i + b - 1]; --b; }
-                K[i + b] = ka;
             }
+            if (lane == 0) { L.nrec = nrec; L.stop2 = stop2; L.tie0 = __ballot(t0) ? 1 : 0; }
         }
+        __syncthreads();
     }
-    if (tid == 0) { B.gstop = 0x7FFFFFFF; B.reason = 0; B.ones = 0; B.nev = 0; B.nnb = 0; B.lnb = -1; }
-    __syncthreads();
-    PB_STAMP(kProfTie);
-    if (B.degenerate) return 2;
-    // ---- evaluate: thread t owns the entries [t per, (t+1) per) of the sorted chunk and keeps them in registers
-    // (table entry, discrepancy, cost, frontier growth) from the evaluation to the sequential rules
-    constexpr int PER = CAP / NT;
-    const int per = (n + NT - 1) / NT;
-    const int i0 = tid * per, i1 = (i0 + per) < n ? (i0 + per) : n;
-    u64 kq[PER], Dq[PER];
-    uchar4 tq4[PER];
-    float cq[PER];
-    int dq[PER];
+    const int nrec = L.nrec, stop2 = L.stop2;
+    tie |= L.tie0 != 0;
+    if (nrec > 0) {    // rule 1 again for the keys behind the first record, with the best they see
+        const u64 r0k = L.rk[0];
+        const unsigned s0 = sumbits(r0k);
 #pragma unroll
-    for (int q = 0; q < PER; ++q) kq[q] = (q < per && i0 + q < n) ? K[i0 + q] : 0ull;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) tq4[q] = tab[(unsigned)kq[q] & 0xFFFFu];        // independent loads, issued together
-    float tmin = __builtin_inff();
-    int tdel = 0;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const bool valid = q < per && i0 + q < n;
-        const PbTep t{tq4[q].x, tq4[q].y, tq4[q].z, tq4[q].w};
-        u64 E;
-        pb_apply(L, t, d0, Dq[q], E);
-        cq[q] = valid ? tep_cost_wide(L, __uint_as_float((unsigned)(kq[q] >> 32)), Dq[q]) : __builtin_inff();
-        dq[q] = valid ? pb_delta(t, P.order) : 0;
-        tmin = __builtin_fminf(tmin, cq[q]);
-        tdel += dq[q];
-    }
-    // exclusive scans over the threads: min of the costs / sum of the frontier growth before my entries
-    const float imin = wave_incl_min(tmin, lane);
-    const int iadd = wave_incl_add(tdel, lane);
-    if (lane == 63) { B.red_f[0][wave] = imin; B.red_i[0][wave] = iadd; }
-    __syncthreads();
-    float before = __shfl_up(imin, 1, 64);
-    if (lane == 0) before = __builtin_inff();
-    int nlb = iadd - tdel, tot_del = 0;
-    for (int w = 0; w < W; ++w) {
-        if (w < wave) { before = __builtin_fminf(before, B.red_f[0][w]); nlb += B.red_i[0][w]; }
-        tot_del += B.red_i[0][w];
-    }
-    before = __builtin_fminf(before, B.best);
-    nlb += B.nlive;
-    PB_STAMP(kProfEval1);
-    // ---- the sequential rules on my entries, assuming no earlier stop
-    int ones = 0, nev = 0, nnb = 0, lnb = -1, lstop = 0x7FFFFFFF, lreason = 0;
-    float lbest = 0.0f;
-    u64 lD = 0;
-    uchar4 lt = make_uchar4(0, 0, 0, 0);
-    // rule 1 of all my entries first -- independent of each other once "the best before entry q" (a running minimum of the
-    // costs: up to the first stop every entry is evaluated) is known, so their exp / divide / CDF reads overlap -- then
-    // the sequential pass
-    bool npq[PER];
-    float w1q[PER];
-    {
-        float bef = before;
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            npq[q] = pb_not_promising(__uint_as_float((unsigned)(kq[q] >> 32)), bef, Fr, P.c4, B.cdfA, B.cdfH, w1q[q]);
-            bef = __builtin_fminf(bef, cq[q]);       // (an invalid entry has cost +inf)
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        if (q < per && i0 + q < n && lstop == 0x7FFFFFFF) {
-            ones += nlb == 1;
-            nlb += dq[q];
-            if (npq[q]) { lstop = i0 + q; lreason = 1; }
-            else {
-                ++nev;
-                if (cq[q] < before) {
-                    before = cq[q]; lnb = i0 + q; ++nnb; lbest = cq[q]; lD = Dq[q]; lt = tq4[q];
-                    if (pb_success(Dq[q], w1q[q], B.tq, Fr)) { lstop = i0 + q; lreason = 2; }
+        for (int k = 0; k < PER; ++k) {
+            if (kq[k] != ~0ull && sumbits(kq[k]) >= s0 && kq[k] != r0k) {
+                int t = 0;
+                for (int u = 0; u < nrec; ++u) { const u64 r = L.rk[u]; t += sumbits(r) < sumbits(kq[k]); tie |= sumbits(r) == sumbits(kq[k]) && r != kq[k]; }
+                if (t > 0) {
+                    float w1;
+                    const bool np = pb_not_promising(__uint_as_float(sumbits(kq[k])), L.rc[t - 1], Fr, P.c4, T0.cdfA, T0.cdfH, w1);
+                    npmask = (npmask & ~(1u << k)) | (np ? 1u << k : 0u);
                 }
             }
         }
     }
-    if (lstop != 0x7FFFFFFF) atomicMin(&B.gstop, lstop);
-    __syncthreads();
-    PB_STAMP(kProfEval2);
-    const int gstop = B.gstop;
-    {   // my entries count if they lie before (or contain) the first stop; wave sums first, one atomic set per wavefront
-        const bool mine = i0 < i1 && i0 <= gstop;
-        int o = mine ? ones : 0, e = mine ? nev : 0, b = mine ? nnb : 0, l = mine ? lnb : -1;
-        o = wave_add_i32(o); e = wave_add_i32(e); b = wave_add_i32(b); l = wave_max_i32(l);
-        if (lane == 0) { atomicAdd(&B.ones, o); atomicAdd(&B.nev, e); atomicAdd(&B.nnb, b); atomicMax(&B.lnb, l); }
-        if (mine && lstop == gstop) B.reason = lreason;
+    PBC_STAMP(kPcSCand);
+    unsigned fs = 0x7FFFFFFFu;     // the smallest sum on which rule 1 fires
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (((npmask >> k) & 1u) && sumbits(kq[k]) < fs) fs = sumbits(kq[k]);
+    const unsigned sF = (unsigned)coop_min<NW>(R, wave_min_i32((int)fs));
+    PBC_STAMP(kPcSMin);
+    int reason = 0;
+    unsigned sstop = 0;
+    if (sF != 0x7FFFFFFFu) { reason = 1; sstop = sF; }
+    if (stop2) {
+        const unsigned sR = sumbits(L.rk[nrec - 1]);
+        if (reason == 1 && sR == sF) tie = true;
+        if (reason == 0 || sR < sF) { reason = 2; sstop = sR; }
     }
-    __syncthreads();
-    if (lnb >= 0 && lnb == B.lnb && i0 <= gstop) {   // the last improvement before the stop is mine
-        u64 E = 1ull << lt.x;
-        if (lt.w > 1) E |= 1ull << lt.y;
-        if (lt.w > 2) E |= 1ull << lt.z;
-        B.best = lbest; B.bestD = lD; B.bestE = E; B.bestidx = B.j + lnb + 1;
+    int nbefore = nrec;
+    if (reason) {
+        nbefore = 0;
+        for (int u = 0; u < nrec; ++u) nbefore += sumbits(L.rk[u]) < sstop;
+        nbefore += reason == 2;
     }
-    __syncthreads();
-    if (tid == 0) {
-        const int npop = gstop != 0x7FFFFFFF ? gstop + 1 : n;
-        B.cmp += 2 * npop - B.ones; B.suc1 += B.nev; B.suc2 += B.nnb;
+    // positions: the keys below the last record that counts, the keys below the stopping sum; ties (one exchange: 12 + 12 + 1 bits)
+    const u64 bk = nbefore > 0 ? L.rk[nbefore - 1] : 0ull;
+    const float bcost = nbefore > 0 ? L.rc[nbefore - 1] : 0.0f;
+    int cb = 0, cs = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (nbefore > 0) { cb += sumbits(kq[k]) < sumbits(bk); tie |= sumbits(kq[k]) == sumbits(bk) && kq[k] != bk; }
+        if (reason == 1) cs += sumbits(kq[k]) < sstop;
     }
-    if constexpr (PROF) { if (tid == 0) B.prof[kProfChunks] += 1; }
-    if (gstop != 0x7FFFFFFF) { stop = B.reason; ntep = B.j + gstop + 1; __syncthreads(); PB_STAMP(kProfCombine); return 1; }
-    __syncthreads();
-    if (tid == 0) { B.j += n; B.nlive += tot_del; }
-    __syncthreads();
-    PB_STAMP(kProfCombine);
+    const int pos = coop_sum<NW>(R, wave_add_i32(cb) + (wave_add_i32(cs) << 13) + (__ballot(tie) ? 1 << 26 : 0));
+    if (wave == 0 && lane == 0) L.nkeys = 0;          // (the next chunk's buffer starts empty)
+    __syncthreads();                                  // (and the candidate / record words are free again)
+    PBC_STAMP(kPcSPos);
+    if (pos >> 26) return -1;
+    const int rank_best = pos & 0x1FFF, rank_stop = reason == 2 ? rank_best : (pos >> 13) & 0x1FFF;
+    if (nbefore > 0) {
+        const PbTep t = pbw_tep((unsigned)bk);
+        u64 E = 1ull << t.p0;
+        if (t.wt > 1) E |= 1ull << t.p1;
+        if (t.wt > 2) E |= 1ull << t.p2;
+        S.best = bcost; S.bestD = parity(t); S.bestE = E;
+        S.bestidx = S.j + rank_best + 1;
+    }
+    S.suc2 += nbefore;
+    if (reason) {
+        S.cmp += 2 * (rank_stop + 1);
+        S.suc1 += reason == 1 ? rank_stop : rank_stop + 1;
+        stop = reason; ntep = S.j + rank_stop + 1;
+        return 1;
+    }
+    S.cmp += 2 * n; S.suc1 += n;
+    S.j += n; S.nlive += deltot;
     return 0;
 }
 
-// per-frame set-up of the workgroup kernels: wavefront 0 prepares the frame, all wavefronts build the byte LUTs
-template <int NT, int CAP>
-__device__ __forceinline__ SearchFrame pb_block_setup(PbBlockLds<NT, CAP> &B, const float *__restrict__ y, long long src, long long f,
-                                                      const unsigned char *__restrict__ perm_in, const u64 *__restrict__ parity_in,
-                                                      const PbParams &P, const PbPrep *__restrict__ prep,
-                                                      int tid)
+// nxt of all 32 rows from the cursors in L.cur (a wavefront that takes a search over in the middle)
+template <int CAP>
+__device__ __forceinline__ void pbw_walk_resume(PbWaveLds<CAP> &L, PbWalk &W, int order, int lane)
 {
-    SearchLds &L = B.s;
-    const int lane = tid & 63, wave = tid >> 6;
-    SearchFrame S{};
-    if (wave == 0) {
-        S = search_prepare_regs<false>(L, y, src, perm_in[f * 128 + lane], perm_in[f * 128 + 64 + lane], parity_in[f * 64 + lane], lane);
-        if (lane == 0) { B.d0 = S.d0; B.degenerate = 0; }
-    } else if (prep && wave == 1) {   // meanwhile: what pb_singles_kernel already computed for this frame
-        const PbPrep &R = prep[f];
-        B.q[lane] = R.q[lane]; B.q[lane + 64] = R.q[lane + 64];
-        B.cdfA[lane] = R.cdfA[lane];
-        if (lane == 0) { B.cdfA[64] = R.cdfA[64]; B.fr = R.fr; }
+    pbw_cursors_load<CAP>(L, W.ecur, lane);
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        float v = pbw_next_sum(L.w, q, lane, (int)((W.ecur[q >> 2] >> (8 * (q & 3))) & 255u), order);
+        asm volatile("" : "+v"(v) : : "memory");
+        W.nxt[q] = v;
     }
-    __syncthreads();
-    for (int b = wave; b < 8; b += NT / 64) build_byte_luts<1>(L.lut + b, &L.w[64 + 8 * b], lane);
-    if (wave == 0) {
-        if (!prep) {
-            const PbFrame Fr = pb_frame_setup(L.w, B.q, B.cdfA, P.c4, P.order, P.nmax, lane);
-            if (lane == 0) B.fr = Fr;
-        }
-        pb_success_terms(B.q, B.tq, lane);
-    }
-    __syncthreads();
-    return S;
 }
 
-// Stage B of a frame of list C: the visit order continues above the bound stage A reached, in chunks of up to 4096
-// TEPs, until a rule fires or the table is exhausted (a full scan of 43 744 TEPs is ~15 chunks).
-template <int NT, int CAP, bool PROF, int MINW = 1>
-__global__ __launch_bounds__(NT, MINW) void pb_heavy_kernel(const float *__restrict__ y, const int *__restrict__ index,
-                                                      const unsigned char *__restrict__ perm_in,
-                                                      const u64 *__restrict__ parity_in, PbParams P,
-                                                      const double *__restrict__ cdf_half,
-                                                      const uchar4 *__restrict__ tab, int *__restrict__ ctl,
-                                                      const int *__restrict__ listC, int *__restrict__ listB, int sub_cap,
-                                                      const PbCarry *__restrict__ carry, const PbPrep *__restrict__ prep, PbOut O,
-                                                      unsigned long long *__restrict__ prof_out)
+// Wavefront 0 alone over the sums (lo, T] that hold n TEPs: the sorted path, in sub-chunks.  L.one.cur holds the cursors of
+// the range's start (all 32 rows); arguments in L.su / L.bs / L.sP, results in L.bs / L.bstate / L.bstop / L.bntep
+// (state 0 / 1 / 2 as in pb_wave_kernel).
+template <int NW>
+__device__ __noinline__ void coop_solo_range(PbCoopLds<NW> &L)
+{
+    constexpr int CAP = kPbWaveCap;
+    const int lane = threadIdx.x & 63;
+    unsigned long long pt[kPwSlots], plast = 0;
+    const PbParams P = L.sP;
+    const PbFrame Fr = L.su.fr;
+    const u64 d0 = L.su.d0;
+    const float Tcap = L.su.T, smax = L.su.smax;
+    float lo = L.su.lo;
+    int done = L.su.done;
+    const int end = done + L.su.n;
+    const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);
+    PbwState S = L.bs;
+    int stop = L.bstop, ntep = L.bntep;
+    wave_fence();
+    PbWalk W;
+    pbw_walk_resume<CAP>(L.one, W, P.order, lane);
+    float tprev = 0.0f, nprev = 0.0f;
+    int state = 0;
+    while (state == 0 && done < end) {
+        float T;
+        int nwalks = 0;
+        const int n = pbw_next_chunk<CAP, false>(L.one, W, P.order, lo, done, nall, P.t2, lane, T, tprev, nprev, nwalks, pt, Tcap);
+        if (n <= 0) { state = 2; break; }
+        wave_fence();
+        const float cmn = lo < 0.0f ? L.one.w[63] : lo, cmx = T < __builtin_inff() ? T : smax;
+        state = pbw_scan_chunk<CAP>(L.one, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep);
+        if (state < 0) state = pbw_process_chunk<CAP, false>(L.one, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep, pt, plast);
+        lo = T;
+        done += n;
+    }
+    wave_fence();
+    if (lane == 0) { L.bs = S; L.bstate = state; L.bstop = stop; L.bntep = ntep; L.nkeys = 0; }
+}
+
+template <int NW, bool PROF>
+__global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const double *__restrict__ cdf_half, int *__restrict__ ctl, int *__restrict__ listB,
+                                                          const unsigned *__restrict__ carry, PbOut O, unsigned long long *__restrict__ prof_out)
 {
     // (dynamic LDS: a hipGraph kernel node with more than 64 KiB of STATIC LDS aborts at replay on ROCm 7.2; the size is
     //  registered once in pb_ctx_init)
-    extern __shared__ __attribute__((aligned(16))) unsigned char pb_heavy_lds[];
-    PbBlockLds<NT, CAP> &B = *reinterpret_cast<PbBlockLds<NT, CAP> *>(pb_heavy_lds);
-    SearchLds &L = B.s;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_coop_lds[];
+    PbcProf Q;
+    if constexpr (PROF) { for (int k = 0; k < kPcSlots; ++k) Q.pc[k] = 0; Q.last = __builtin_amdgcn_s_memtime(); }
+    PbCoopLds<NW> &L = *reinterpret_cast<PbCoopLds<NW> *>(pb_coop_lds);
+    constexpr int NI = 32 / NW;
+    static_assert(64 * NW >= 64 + kPbRecPrefix, "wavefronts 1.. copy a record's tables in one go");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // (list C holds at most kPbHeavyCap frames: one length word, one ticket word)
     const int lenc = ctl[kPbCtlLenC];
-    const int nlist = lenc < kPbHeavyCap ? lenc : kPbHeavyCap;
+    const int nlist = lenc < kPbCoopFrames ? lenc : kPbCoopFrames;
     if ((int)blockIdx.x >= nlist) return;      // (more workgroups than frames -- or nothing handed on at all: leave before any set-up)
-    const int nall = P.order == 2 ? kPbTriples0 : kPbTabSize;
-    if (tid < 65) B.cdfH[tid] = cdf_half[tid];
-    PbItems<NT> I;
-    pb_items_static(I, tab, P.order, tid);
-    if constexpr (PROF) { if (tid < 24) B.prof[tid] = 0; if (tid == 0) B.prof_last = __builtin_amdgcn_s_memtime(); }
-
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) B.ticket = atomicAdd(&ctl[kPbCtlTicketC], 1);
-        __syncthreads();
-        const int tk = B.ticket;
+    const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);
+    if (wave == 0) {
+        L.one.cdfH[lane] = (float)cdf_half[lane];
+        if (lane == 0) { L.one.cdfH[64] = (float)cdf_half[64]; L.ticket[0] = atomicAdd(&ctl[kPbCtlTicketC], 1); L.sP = P; }
+    }
+    CoopRed<NW> R{L.red, 0, wave, lane};
+    __syncthreads();
+    for (int it = 0;; ++it) {
+        // frames are handed out by ticket; the NEXT frame's ticket is drawn now and is back long before it is needed
+        int tk = L.ticket[it & 1];
         if (tk >= nlist) break;
-        const long long f = listC[tk];
-        const long long src = index ? index[f] : f;
-        const SearchFrame S = pb_block_setup(B, y, src, f, perm_in, parity_in, P, prep, tid);
-        if (tid == 0) {
-            const PbCarry c = carry[tk];
-            B.lo = c.lo; B.best = c.best; B.j = c.j; B.nlive = c.nlive; B.cmp = c.cmp; B.suc1 = c.suc1; B.suc2 = c.suc2;
-            B.bestidx = c.bestidx; B.bestD = c.bestD; B.bestE = c.bestE;
+        if (tid == 0) { L.ticket[(it + 1) & 1] = atomicAdd(&ctl[kPbCtlTicketC], 1); L.nkeys = 0; }
+        const unsigned *rec = carry + (long long)tk * kPbRecWords;
+        // the frame's tables: one load per thread (wavefront 0 may still be writing the previous frame's codeword out)
+        if (tid >= 64 && tid < 64 + kPbRecPrefix) reinterpret_cast<unsigned *>(&L.one)[tid - 64] = rec[tid - 64];
+        const PbCarry &c = *reinterpret_cast<const PbCarry *>(rec + kPbRecScalars);
+        PbFrame Fr = c.fr;
+        u64 d0 = c.d0;
+        PbwState S;
+        S.best = c.best; S.j = c.j; S.nlive = c.nlive; S.cmp = c.cmp; S.suc1 = c.suc1; S.suc2 = c.suc2; S.bestidx = c.bestidx;
+        S.bestD = c.bestD; S.bestE = c.bestE;
+        float lo = c.lo;
+        int done = S.j;
+        unsigned ecur = 0;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int q, l;
+            coop_item<NW>(wave, j, lane, q, l);
+            ecur |= ((rec[kPbRecCur + (q >> 2) * 64 + l] >> (8 * (q & 3))) & 255u) << (8 * j);
         }
+        L.cur[wave][lane] = ecur;
         __syncthreads();
-        PB_STAMP(kProfSetup);
-        const PbFrame Fr = B.fr;
-        const u64 d0 = B.d0;
+        float nxt[NI];
+        coop_refresh<NW>(nxt, ecur, L.one.w, P.order, lane, wave);
+        float smax = P.order > 2 ? (L.one.w[0] + L.one.w[1]) + L.one.w[2] : (P.order > 1 ? L.one.w[0] + L.one.w[1] : L.one.w[0]);
         int stop = 0, ntep = P.nmax, state = 0;
-        // ---- chunks of increasing sums (aimed at 3/4 of the capacity) until a rule fires or the table is exhausted
-        float lo = B.lo;
-        int done = B.j;
-        pb_items_frame(I, L.w, lo);
-        const float smax = P.order > 2 ? (L.w[0] + L.w[1]) + L.w[2] : L.w[0] + L.w[1];
+        float tprev = 0.0f, nprev = 0.0f;
+        PBC_STAMP(kPcSetup);
         while (state == 0 && done < nall) {
-            int n, run;
-            const float T = pb_pick_bound(B, I, L.w, P.order, lo, done, nall, P.t3, lane, wave, n, run);
-            PB_STAMP(kProfHist);
+            const unsigned eprev = ecur;
+            float T;
+            int n = coop_next_chunk<NW, PROF>(L, R, nxt, ecur, P.order, lo, done, nall, P.t3, lane, wave, T, tprev, nprev, Q);
+            PBC_STAMP(kPcWalk);
             if (n < 0) { state = 2; break; }
-            pb_items_write(B, I, L.w, run);
-            __syncthreads();
-            PB_STAMP(kProfGather);
-            state = pb_process_chunk<NT, CAP, PROF>(B, tab, P, Fr, d0, n, lo < 0.0f ? L.w[63] : lo, T < __builtin_inff() ? T : smax, tid, stop, ntep);
+            if (n == 0) break;
+            if constexpr (PROF) { Q.pc[kPcChunks] += 1; Q.pc[kPcKeys] += n; }
+            const float cmn = lo < 0.0f ? L.one.w[63] : lo, cmx = T < __builtin_inff() ? T : smax;
+            state = coop_scan_chunk<NW, PROF>(L, R, P, Fr, d0, n, cmn, cmx, lane, wave, S, stop, ntep, Q);
+            PBC_STAMP(kPcScan);
+            if (state < 0) {
+                if constexpr (PROF) { Q.pc[kPcSolos] += 1; Q.pc[kPcSoloKeys] += n; }
+                // wavefront 0 redoes the chunk alone from the cursors the chunk started with
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    int q, l;
+                    coop_item<NW>(wave, j, lane, q, l);
+                    reinterpret_cast<unsigned char *>(&L.one.cur[q >> 2][l])[q & 3] = (unsigned char)((eprev >> (8 * j)) & 255u);
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    // (everything this wavefront needs afterwards is parked in LDS around the call: see PbCoopLds::sv)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) L.sv[j][lane] = nxt[j];
+                    L.sv[NI][lane] = __uint_as_float(ecur);
+                    if (lane == 0) {
+                        L.su.fr = Fr; L.su.d0 = d0; L.su.lo = lo; L.su.T = T; L.su.tprev = tprev; L.su.nprev = nprev; L.su.smax = smax;
+                        L.su.done = done; L.su.n = n; L.su.seq = R.seq; L.su.it = it; L.su.tk = tk;
+                        L.bs = S; L.bstop = stop; L.bntep = ntep;
+                    }
+                    wave_fence();
+                    coop_solo_range<NW>(L);
+                    wave_fence();
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) nxt[j] = L.sv[j][lane];
+                    ecur = __float_as_uint(L.sv[NI][lane]);
+                    Fr = L.su.fr; d0 = L.su.d0; lo = L.su.lo; T = L.su.T; tprev = L.su.tprev; nprev = L.su.nprev; smax = L.su.smax;
+                    done = L.su.done; n = L.su.n; R.seq = L.su.seq; it = L.su.it; tk = L.su.tk;
+                    rec = carry + (long long)tk * kPbRecWords;
+                }
+                __syncthreads();
+                S = L.bs; state = L.bstate; stop = L.bstop; ntep = L.bntep;
+                PBC_STAMP(kPcSolo);
+            }
             lo = T;
             done += n;
         }
-        __syncthreads();
-        if (state == 2) {
-            if (tid == 0) listB[atomicAdd(&ctl[kPbCtlLenB], 1)] = (int)f;
-            continue;
+        __syncthreads();                        // (every wavefront is through with the frame's tables)
+        if (wave == 0) {
+            if (state == 2) {   // massive ties: the literal list replay decodes this frame
+                if (lane == 0) listB[atomicAdd(&ctl[kPbCtlLenB], 1)] = (int)reinterpret_cast<const PbCarry *>(rec + kPbRecScalars)->f;
+            } else {
+                const PbCarry &c2 = *reinterpret_cast<const PbCarry *>(rec + kPbRecScalars);
+                const u64 hm = c2.hm, hp = c2.hp;
+                const long long f = c2.f;
+                const unsigned po = rec[kPbRecPerm + lane];
+                const int o1 = (int)(po & 255u), o2 = (int)(po >> 8);
+                if (lane < 2) L.one.cw[lane] = 0;
+                wave_fence();
+                const u64 mrb_bits = hm ^ S.bestE, par_bits = S.bestD ^ hp;
+                if ((mrb_bits >> lane) & 1) atomicOr(&L.one.cw[o1 >> 6], 1ull << (o1 & 63));
+                if ((par_bits >> lane) & 1) atomicOr(&L.one.cw[o2 >> 6], 1ull << (o2 & 63));
+                wave_fence();
+                if (lane < 2) O.cw[f * 2 + lane] = L.one.cw[lane];
+                if (lane == 0) {
+                    if (O.metric) O.metric[f] = S.best;
+                    if (O.best) O.best[f] = S.bestidx;
+                    if (O.ntep) O.ntep[f] = ntep;
+                    if (O.aux) { O.aux[f * 4] = S.cmp; O.aux[f * 4 + 1] = S.suc1; O.aux[f * 4 + 2] = S.suc2; O.aux[f * 4 + 3] = stop; }
+                }
+            }
         }
-        if (wave == 0)
-            pb_write(L, S, O, f, lane, B.bestE, B.bestD, B.best, B.bestidx, ntep, B.cmp, B.suc1, B.suc2, stop);
-        if constexpr (PROF) { if (tid == 0) B.prof[kProfFrames] += 1; }
-        PB_STAMP(kProfFinish);
+        PBC_STAMP(kPcOut);
+        if constexpr (PROF) Q.pc[kPcFrames] += 1;
     }
-    if constexpr (PROF) { __syncthreads(); if (tid < 21) atomicAdd(&prof_out[tid], B.prof[tid]); else if (tid < 24) atomicMax(&prof_out[tid], B.prof[tid]); }
+    if constexpr (PROF) { if (tid == 0 && Q.pc[kPcFrames]) for (int k = 0; k < kPcSlots; ++k) atomicAdd(&prof_out[k], Q.pc[k]); }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2175,24 +2327,13 @@ __global__ __launch_bounds__(64) void pb_ctl_clear_kernel(int *__restrict__ ctl)
     for (int i = threadIdx.x; i < kPbCtlInts; i += 64) ctl[i] = 0;
 }
 
-int pb_ctx_init(ldpc_ctx *ctx)
+int pb_ctx_init(ldpc_ctx *)
 {
-    // (the chunk kernel generates its TEPs from the sorted reliabilities; the latency-shaped kernel reads this table: ids
-    //  0..63 = {63 - id}, 64..2079 the pairs, 2080..43743 the triples, each class by DESCENDING smallest position)
-    OsdState *st = state(ctx);
-    LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_heavy_kernel<1024, 4096, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)sizeof(PbBlockLds<1024, 4096>)));
-    std::vector<uchar4> tab;
-    tab.reserve(kPbTabSize);
-    for (int p = 63; p >= 0; --p) tab.push_back(make_uchar4((unsigned char)p, 0, 0, 1));
-    for (int p0 = 62; p0 >= 0; --p0)
-        for (int p1 = p0 + 1; p1 < 64; ++p1) tab.push_back(make_uchar4((unsigned char)p0, (unsigned char)p1, 0, 2));
-    for (int p0 = 61; p0 >= 0; --p0)
-        for (int p1 = p0 + 1; p1 < 63; ++p1)
-            for (int p2 = p1 + 1; p2 < 64; ++p2) tab.push_back(make_uchar4((unsigned char)p0, (unsigned char)p1, (unsigned char)p2, 3));
-    if ((int)tab.size() != kPbTabSize) return fail(LDPC_E_CODE, "PB-OSD table has %zu entries", tab.size());
-    LDPC_HIP(hipMalloc((void **)&st->d_pb_tab, sizeof(uchar4) * tab.size()));
-    LDPC_HIP(hipMemcpy(st->d_pb_tab, tab.data(), sizeof(uchar4) * tab.size(), hipMemcpyHostToDevice));
+    static_assert(sizeof(PbCoopLds<kPbCoopW>) <= 160 * 1024, "one workgroup per CU");
+    LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_coop_kernel<kPbCoopW, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(PbCoopLds<kPbCoopW>)));
+    LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_coop_kernel<kPbCoopW, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(PbCoopLds<kPbCoopW>)));
     return LDPC_OK;
 }
 
@@ -2229,8 +2370,8 @@ static int stream_ws_pb(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int64_t sp
         (void)hipFree(w.d_pb_prep); w.d_pb_prep = nullptr;
         (void)hipFree(w.d_pb_carry); w.d_pb_carry = nullptr;
         const int64_t sub_cap = (frames + kPbSub - 1) / kPbSub;
-        if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * (2 * (size_t)kPbSub * (size_t)sub_cap + kPbHeavyCap)) != hipSuccess ||
-            hipMalloc(&w.d_pb_carry, sizeof(PbCarry) * kPbHeavyCap) != hipSuccess ||
+        if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * (2 * (size_t)kPbSub * (size_t)sub_cap)) != hipSuccess ||
+            hipMalloc(&w.d_pb_carry, sizeof(unsigned) * kPbRecWords * (size_t)kPbHeavyCap) != hipSuccess ||
             hipMalloc(&w.d_pb_prep, sizeof(PbPrep) * (size_t)frames) != hipSuccess)
             return fail(LDPC_E_NOMEM, "PB-OSD frame lists for %lld frames could not be allocated", (long long)frames);
         w.pb_cap = frames; w.pb_sub_cap = sub_cap;
@@ -2275,7 +2416,11 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     // chunk kernel's throughput is what counts and the 1024-thread launch only adds its own time.
     pp.handoff_maxlen = 1024;
     if (const char *e = getenv("LDPC_PB_HANDOFF_MAXLEN")) pp.handoff_maxlen = atoi(e);
+    pp.budget_s = pp.budget / 8; pp.budget_m = pp.budget / 4;
     if (const char *e = getenv("LDPC_PB_BUDGET")) pp.budget = atoi(e);   // (tuning aids)
+    if (const char *e = getenv("LDPC_PB_BUDGET_S")) pp.budget_s = atoi(e);
+    if (const char *e = getenv("LDPC_PB_BUDGET_M")) pp.budget_m = atoi(e);
+    if (const char *e = getenv("LDPC_PB_T3")) pp.t3 = atoi(e);
     if (const char *e = getenv("LDPC_PB_T2")) pp.t2 = atoi(e);
     if (const char *e = getenv("LDPC_PB_T1")) pp.t1 = atoi(e);
    // chunk targets: the first chunk's count is only guessed (+-40 %), the others follow the growth of the counts
@@ -2283,8 +2428,8 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     const int mode = (p->reserved & 4) ? 2 : ((p->reserved & 2) ? 1 : 0);
     PbOut O{reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep, reinterpret_cast<int *>(p->d_aux)};
     const int64_t list_len = (int64_t)kPbSub * w->pb_sub_cap;   // >= pb_cap
-    int *listA = w->d_pb_list, *listB = w->d_pb_list + list_len, *listC = w->d_pb_list + 2 * list_len;
-    PbCarry *carry = reinterpret_cast<PbCarry *>(w->d_pb_carry);
+    int *listA = w->d_pb_list, *listB = w->d_pb_list + list_len;
+    unsigned *carry = reinterpret_cast<unsigned *>(w->d_pb_carry);      // [kPbHeavyCap] records of kPbRecWords words
     const int sub_cap = (int)w->pb_sub_cap;
     PbPrep *prep_w = reinterpret_cast<PbPrep *>(w->d_pb_prep);
     hipLaunchKernelGGL(pb_ctl_clear_kernel, dim3(1), dim3(64), 0, s, w->d_pb_ctl);
@@ -2313,13 +2458,13 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     const PbPrep *prep = mode == 0 ? prep_w : nullptr;    // (cross-check routes skip the stage that fills it)
     if (!profile_s) {
         hipLaunchKernelGGL((pb_wave_kernel<kPbWaveCap, false>), dim3(g2), dim3(64), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half, w->d_pb_ctl,
-                           listA, listB, sub_cap, listC, carry, prep, O, (unsigned long long *)nullptr);
+                           listA, listB, sub_cap, carry, prep, O, (unsigned long long *)nullptr);
     } else {
         static unsigned long long *d_pw = nullptr;
         if (!d_pw) LDPC_HIP(hipMalloc((void **)&d_pw, sizeof(unsigned long long) * kPwSlots));
         LDPC_HIP(hipMemsetAsync(d_pw, 0, sizeof(unsigned long long) * kPwSlots, s));
         hipLaunchKernelGGL((pb_wave_kernel<kPbWaveCap, true>), dim3(g2), dim3(64), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half, w->d_pb_ctl,
-                           listA, listB, sub_cap, listC, carry, prep, O, d_pw);
+                           listA, listB, sub_cap, carry, prep, O, d_pw);
         unsigned long long h[kPwSlots];
         LDPC_HIP(hipMemcpyAsync(h, d_pw, sizeof(h), hipMemcpyDeviceToHost, s));
         LDPC_HIP(hipStreamSynchronize(s));
@@ -2329,9 +2474,24 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
         fprintf(stderr, "\n");
     }
     // the long searches the chunk kernel handed on (at most kPbHeavyCap; the workgroups find an empty list otherwise)
-    hipLaunchKernelGGL((pb_heavy_kernel<1024, 4096, false>), dim3((unsigned)(F < kPbHeavyCap ? F : kPbHeavyCap)), dim3(1024), sizeof(PbBlockLds<1024, 4096>), s,
-                       d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half, st->d_pb_tab, w->d_pb_ctl, listC, listB, sub_cap, carry, prep, O,
-                       (unsigned long long *)nullptr);
+    const unsigned g4 = (unsigned)(F < kPbCoopGrid ? F : kPbCoopGrid);
+    if (!profile_s) {
+        hipLaunchKernelGGL((pb_coop_kernel<kPbCoopW, false>), dim3(g4), dim3(64 * kPbCoopW), sizeof(PbCoopLds<kPbCoopW>), s,
+                           pp, st->d_cdf_half, w->d_pb_ctl, listB, carry, O, (unsigned long long *)nullptr);
+    } else {
+        static unsigned long long *d_pc = nullptr;
+        if (!d_pc) LDPC_HIP(hipMalloc((void **)&d_pc, sizeof(unsigned long long) * kPcSlots));
+        LDPC_HIP(hipMemsetAsync(d_pc, 0, sizeof(unsigned long long) * kPcSlots, s));
+        hipLaunchKernelGGL((pb_coop_kernel<kPbCoopW, true>), dim3(g4), dim3(64 * kPbCoopW), sizeof(PbCoopLds<kPbCoopW>), s,
+                           pp, st->d_cdf_half, w->d_pb_ctl, listB, carry, O, d_pc);
+        unsigned long long h[kPcSlots];
+        LDPC_HIP(hipMemcpyAsync(h, d_pc, sizeof(h), hipMemcpyDeviceToHost, s));
+        LDPC_HIP(hipStreamSynchronize(s));
+        static const char *names[kPcSlots] = {"setup", "walk", "scan", "solo", "out", "FRAMES", "CHUNKS", "SOLOS", "SOLOKEYS", "KEYS", "WALKS", "TRIPS", "w_list", "w_dense", "w_collect", "w_barrier", "w_pick", "s_probe", "s_keys", "s_bar1", "s_surv", "s_bar2", "s_cand", "s_min", "s_pos"};
+        fprintf(stderr, "[LDPC_PB_PROFILE] workgroup kernel, shader-clock ticks of thread 0 summed over workgroups:");
+        for (int q = 0; q < kPcSlots; ++q) fprintf(stderr, " %s=%llu", names[q], h[q]);
+        fprintf(stderr, "\n");
+    }
     const unsigned g3 = (unsigned)(want < kPbSeqBlocks ? (want < 1 ? 1 : want) : kPbSeqBlocks);
     hipLaunchKernelGGL(pb_seq_kernel, dim3(g3), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half,
                        reinterpret_cast<PbEntry *>(w->d_pb_spill), (long long)w->pb_spill_stride, w->d_pb_ctl, listB, O);

@@ -15,8 +15,8 @@ struct StreamWs {
     int *d_index_safe = nullptr;      // ldpc_osd_params.y_frames: the sanitised copy of the caller's frame list [index_cap]
     int64_t index_cap = 0;
     int *d_pb_ctl = nullptr;          // PB-OSD: list lengths and tickets (kPbCtlInts ints, zeroed per call)
-    int *d_pb_list = nullptr;         // PB-OSD: [2][kPbSub * pb_sub_cap] frames handed on: list A (chunk kernel), B (list replay); then list C [kPbHeavyCap]
-    void *d_pb_carry = nullptr;       // PB-OSD: [kPbHeavyCap] search state of the frames on list C (latency-shaped kernel)
+    int *d_pb_list = nullptr;         // PB-OSD: [2][kPbSub * pb_sub_cap] frames handed on: list A (chunk kernel), B (list replay)
+    void *d_pb_carry = nullptr;       // PB-OSD: [kPbHeavyCap] records of the long searches handed to the workgroup kernel ("list C")
     void *d_pb_prep = nullptr;        // PB-OSD: [pb_cap] per-frame probabilities / CDF table of the frames handed on (1 KiB each)
     int64_t pb_cap = 0, pb_sub_cap = 0;
     void *d_pb_spill = nullptr;       // PB-OSD sequential kernel: frontier overflow [waves][stride]
@@ -32,7 +32,8 @@ constexpr int kPbSub = 16, kPbCtlLine = 32;
 constexpr int kPbCtlLenA = 0, kPbCtlLenB = kPbSub * kPbCtlLine, kPbCtlTicketB = kPbCtlLenB + kPbCtlLine;
 constexpr int kPbCtlLenC = kPbCtlTicketB + kPbCtlLine, kPbCtlTicketC = kPbCtlLenC + kPbCtlLine;
 constexpr int kPbCtlInts = kPbCtlTicketC + kPbCtlLine;
-constexpr int kPbHeavyCap = 1024;     // long searches a call may hand to the latency-shaped kernel (four per CU)
+constexpr int kPbHeavyCap = 4096;     // long searches a call may hand to the workgroup-per-frame kernel
+constexpr int kPbCoopFrames = kPbHeavyCap;
 constexpr int kPbSeqBlocks = 64;      // grid of the sequential PB kernel (each of its 4 x 64 waves owns a spill area)
 
 struct OsdState {
@@ -40,7 +41,6 @@ struct OsdState {
     uchar4 *d_tep_fs = nullptr;       // FS visit order, weight classes 1..3 back to back
     int *d_base2 = nullptr;           // order-2 ranks: number of index pairs with a larger sum
     double *d_cdf_half = nullptr;     // PB-OSD: P[Bin(64, 1/2) <= b], b = 0..64
-    uchar4 *d_pb_tab = nullptr;       // PB-OSD, latency-shaped kernel: TEPs by weight class, each class by descending smallest position
     unsigned long long *d_index_errors = nullptr;   // ldpc_osd_params.y_frames: out-of-range entries met so far
     int fs_off[4] = {0, 0, 0, 0}, fs_cnt[4] = {0, 0, 0, 0};
     std::mutex mu;                    // guards `ws` and `reserve_frames`

@@ -214,6 +214,7 @@ __device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1,
     bool deficient = false;   // (no early exit from the loop: it would make the compiler guard every step)
     int nrho = 63 - rho;   // the loop carries 63 - rho: "bit rho of cj" is then the sign of cj << nrho
     u64 ge_i = ~0ull;      // lanes (logical rows) >= i
+#pragma unroll
     for (int i = 0; i < kOsdK; ++i, ge_i <<= 1) {
         u64 cj = readlane64(C1, i);
         u64 bal = ge_sign_ballot((unsigned)((cj << nrho) >> 32)) & ge_i;
