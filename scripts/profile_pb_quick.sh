@@ -15,7 +15,7 @@ python3 - <<PY
 import json
 d=json.load(open("$O/${T}_pmc.json"))
 for k,v in d["per_launch_mean"].items():
-    if "pb_wave" in k:
+    if "pb_wave" in k or "pb_coop" in k:
         wc=v["SQ_WAVE_CYCLES"]; print(k); print({c:round(x/1e6,1) for c,x in v.items() if c.startswith("SQ")})
         print("wait_any %.2f wait_inst %.2f valu_active/wave_cycles %.2f  valu_issue_frac(per SIMD) %.2f" % (v["SQ_WAIT_ANY"]/wc, v["SQ_WAIT_INST_ANY"]/wc, v["SQ_ACTIVE_INST_VALU"]/wc, v.get("valu_issue_frac",0)))
 PY

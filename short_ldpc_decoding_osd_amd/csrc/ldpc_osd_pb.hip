@@ -82,6 +82,7 @@ struct PbParams {
     int t1, t2;                  // chunk targets: first chunk / later chunks
     int t3, budget;              // chunk target of the workgroup kernel; TEPs after which a frame may be handed to it
     int budget_s, budget_m;      // ... when its sub-list is short (< 128 frames) / of medium length (< 448)
+    int coop_lifo;
     int handoff_maxlen;          // ... if its sub-list of list A holds fewer frames than this (many searches: throughput counts, none leaves)
     float c4;
     long long cmin_off;          // offset of the spilled chunk minima inside a wave's global area
@@ -1472,50 +1473,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
 // ---------------------------------------------------------------------------------------
 constexpr int kCoopCap = 4096;        // keys of a chunk, all wavefronts together
 constexpr int kCoopMaxCand = 64;
+constexpr int kCoopWaveKeys = 512;    // keys of a chunk from one wavefront (a sixteenth of the items: 256 +- 10 % when the chunk is full)
 constexpr int kPbCoopW = 16;          // wavefronts per frame
 constexpr int kPbCoopGrid = 256;      // workgroups (frames are handed out by ticket)
 
 template <int NW>
 struct __attribute__((aligned(16))) PbCoopLds {
-    static constexpr int NI = 32 / NW;                    // item rows per wavefront
-    static constexpr int WCAP = 3 * kCoopCap / NW;        // members one wavefront may emit per chunk: three times the mean
-    static_assert(NI >= 1 && NI <= 4, "a wavefront's cursors are the bytes of one word");
+    static constexpr int NI = 32 / NW;                    // items per lane
     PbWaveLds<kPbWaveCap> one;        // the frame's tables (tail, P, w, tq, cdf); the rest of it is wavefront 0's when it works alone
     u64 keys[kCoopCap];
-    unsigned list[NW][WCAP + 64 * NI];
-    unsigned cur[NW][64];             // tentative cursors: byte j of cur[v][lane] = item j of that lane (coop_item)
+    unsigned short slist[NW][kCoopWaveKeys];              // a wavefront's keys that the cost bound could not rule out
+    uint4 desc[NW][64];                                    // a wavefront's items with members in the chunk (emission)
     u64 ck[kCoopMaxCand], rk[kCoopMaxCand];
     float cc[kCoopMaxCand], rc[kCoopMaxCand];
-    int red[8][NW];
-    int nkeys, ncand, nrec, stop2, tie0, ticket[2];
+    int red[8][NW], red2[8][NW];
+    int ncand[2], nrec, stop2, tie0, ticket[2];
     PbwState bs;                      // wavefront 0 -> all, after it worked alone
     int bstate, bstop, bntep;
     // What wavefront 0 holds in registers when it leaves for coop_solo_range, parked here and read back afterwards: a value
     // that is live across the call costs a callee-saved register or a scratch slot on EVERY path through the kernel (the
     // call alone took the kernel from 119 VGPRs and no scratch to 128 VGPRs and 101 spilled ones, reloaded inside the walk's
     // loops), a value that is stored before it and loaded after it costs nothing anywhere else.
-    float sv[32 / NW + 1][64];
+    int sv[32 / NW][64];
     struct {
         PbFrame fr;
         u64 d0;
         float lo, T, tprev, nprev, smax;
-        int done, n, seq, it, tk;
+        int done, n, seq, par, it, tk;
     } su;
     PbParams sP;
+    unsigned long long prof[32];      // diagnostic build only
 };
 
 // in-kernel stamps of the diagnostic instantiation (thread 0 of the workgroup), as PBW_STAMP above
 enum { kPcSetup = 0, kPcWalk, kPcScan, kPcSolo, kPcOut, kPcFrames, kPcChunks, kPcSolos, kPcSoloKeys, kPcKeys,
        kPcWalks, kPcTrips, kPcWList, kPcWDense, kPcWCollect, kPcWBarrier, kPcWPick, kPcSProbe, kPcSKeys, kPcSBar1, kPcSSurv, kPcSBar2, kPcSCand, kPcSMin, kPcSPos, kPcSlots };
 struct PbcProf {
-    unsigned long long pc[kPcSlots], last;
+    unsigned long long *pc;      // the workgroup's counters (LDS): registers would cost the diagnostic build ~50 VGPRs and distort it
+    unsigned long long last;
 };
-#define PBC_STAMP(k) do { if constexpr (PROF) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); Q.pc[k] += now__ - Q.last; Q.last = now__; } } while (0)
+#define PBC_STAMP(k) do { if constexpr (PROF) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) Q.pc[k] += now__ - Q.last; Q.last = now__; } } while (0)
+#define PBC_COUNT(k, v) do { if constexpr (PROF) { if (threadIdx.x == 0) Q.pc[k] += (v); } } while (0)
 
 template <int NW>
 struct CoopRed {
     int (*buf)[NW];
-    int seq, wave, lane;
+    int seq, wave, lane, par;
 };
 // sum / minimum of one int per wavefront, the same value in every lane of every wavefront (one barrier; eight rotating slots:
 // a slot is rewritten seven barriers after its last reader)
@@ -1575,105 +1578,65 @@ __device__ __forceinline__ float pbw_next_sum(const float *w, int q, int l, int 
     return live ? s : pbw_nan();
 }
 
+// A wavefront's items in registers: item j of this lane is (row q, lane l) = coop_item(v, j, lane); sb = the sum of its fixed
+// positions, members are m in (base, 63] visited downwards from a - 1 (a = cursor: [a, 64) are visited), key = code | m << sh.
+template <int NI>
+struct CoopItems {
+    float sb[NI];
+    int base[NI], sh[NI], a[NI];
+    unsigned code[NI];
+};
 template <int NW>
-__device__ __forceinline__ void coop_refresh(float (&nxt)[32 / NW], unsigned cur, const float *w, int order, int lane, int wave)
+__device__ __forceinline__ void coop_items_init(CoopItems<32 / NW> &I, const float *w, int order, int lane, int wave)
 {
 #pragma unroll
     for (int j = 0; j < 32 / NW; ++j) {
         int q, l;
         coop_item<NW>(wave, j, lane, q, l);
-        nxt[j] = pbw_next_sum(w, q, l, (int)((cur >> (8 * j)) & 255u), order);
-    }
-}
-
-// pbw_walk (see there: list / dense / collect) over one wavefront's rows, the keys into the workgroup's buffer.
-// cnt = members this wavefront emitted since the chunk began; returns the new count, -1: the buffer (or this wavefront's
-// list) is full -- the walk stopped half way, nxt still describes the cursors it STARTED from.
-template <int NW, bool PROF>
-__device__ __forceinline__ int coop_walk(PbCoopLds<NW> &L, float (&nxt)[32 / NW], float T, int cnt, int lane, int wave, PbcProf &Q)
-{
-    constexpr int NI = 32 / NW, WCAP = PbCoopLds<NW>::WCAP;
-    unsigned *const list = L.list[wave];       // entry: j | owner lane << 2 | first slot << 8
-    unsigned *const cur = L.cur[wave];
-    const float *w = L.one.w;
-    int tail = 0;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const bool pend = nxt[j] <= T;
-        const u64 act = __ballot(pend);
-        if (act) {
-            const int p = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
-            if (pend) list[p] = (unsigned)j | ((unsigned)lane << 2) | ((unsigned)p << 8);
-            tail += __popcll(act);
-        }
-    }
-    PBC_STAMP(kPcWList);
-    if (tail == 0) return cnt;
-    wave_fence();
-    int head = 0;
-    bool over = false;
-    while (head < tail) {
-        if constexpr (PROF) Q.pc[kPcTrips] += 1;
-        const int e = head + lane;
-        const bool has = e < tail;
-        const unsigned ent = has ? list[e] : 0u;
-        const int j = (int)(ent & 3u), ol = (int)((ent >> 2) & 63u);     // the entry's owner
-        int q, l;
-        coop_item<NW>(wave, j, ol, q, l);
         const PbwItem it = pbw_item_rt(q, l);
-        unsigned char *const cb = reinterpret_cast<unsigned char *>(&cur[ol]) + j;
-        const int a = has ? (int)*cb : 1;
-        const float sbv = q < 31 ? w[it.i] + w[it.j] : (l <= 62 ? w[l] : 0.0f);
-        const int m = a - 1;
-        const float s = sbv + w[m], s2 = sbv + w[m > 0 ? m - 1 : 0], s3 = sbv + w[m > 1 ? m - 2 : 0];
-        const bool two = has && m > it.base + 1 && s2 <= T;
-        const int mlast = two ? m - 1 : m;
-        const float nx = mlast > it.base + 1 ? (two ? s3 : s2) : pbw_nan();
-        const u64 act = __ballot(has), act2 = __ballot(two);
-        const int c1 = __popcll(act), c2 = __popcll(act2);
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&L.nkeys, c1 + c2);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base + c1 + c2 > kCoopCap || cnt + c1 + c2 > WCAP) { over = true; break; }
-        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
-        const int pos2 = base + c1 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act2, 0u));
-        const bool again = has && nx <= T;
-        const u64 more = __ballot(again);
-        const int nt = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(more >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)more, 0u));
-        wave_fence();                    // (every lane has read its entry: the slots may be written now)
-        if (has) {
-            L.keys[pos] = ((u64)__float_as_uint(s) << 32) | (it.code | ((unsigned)m << it.sh));
-            if (two) L.keys[pos2] = ((u64)__float_as_uint(s2) << 32) | (it.code | ((unsigned)(m - 1) << it.sh));
-            *cb = (unsigned char)mlast;
-            if (again) list[nt] = ent; else list[ent >> 8] = __float_as_uint(nx);
-        }
-        cnt += c1 + c2;
-        head = head + 64 < tail ? head + 64 : tail;
-        tail += __popcll(more);          // (<= 64 NI + members emitted <= the list's size)
-        wave_fence();
+        const bool live = q < 31 ? order > 2 : (order > 1 || l == 63);
+        I.sb[j] = q < 31 ? w[it.i] + w[it.j] : (l <= 62 ? w[l] : 0.0f);
+        I.base[j] = live ? it.base : 64;      // (an item the order excludes: no members)
+        I.sh[j] = it.sh; I.code[j] = it.code;
     }
-    PBC_STAMP(kPcWDense);
-    if (over) return -1;
-    int slot0 = 0;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const bool pend = nxt[j] <= T;
-        const u64 act = __ballot(pend);
-        const int p = slot0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
-        const float v = __uint_as_float(list[p]);
-        nxt[j] = pend ? v : nxt[j];
-        slot0 += __popcll(act);
-    }
-    PBC_STAMP(kPcWCollect);
-    return cnt;
 }
 
-// pbw_next_chunk for the workgroup: the same T in every wavefront, sized by the SUM of their counts (one barrier per
-// walk).  Returns the chunk's size (keys L.keys[0 .. n), cursors committed to ecur), -1: cannot be split, 0: nothing left.
-template <int NW, bool PROF>
-__device__ __forceinline__ int coop_next_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R, float (&nxt)[32 / NW], unsigned &ecur, int order, float lo, int done,
-                                               int nall, int target, int lane, int wave, float &Tout, float &tprev, float &nprev, PbcProf &Q)
+// The members of every item with sum <= T beyond its cursor: sums fall as the position rises, so they are the positions
+// [first, a) and `first` is found by bisection (7 steps of one LDS read, the items of a lane side by side).  Nothing is
+// written: the count of a bound is a pure function of the cursors, a bound that gives too many or too few keys costs one
+// more count, and the keys are generated once, for the bound that is taken (the round-3 list walk emitted as it went and
+// rolled the cursors back: a chain of four dependent LDS round trips per 64 entries, ~2000 cycles each, and a list per wavefront).
+template <int NI>
+__device__ __forceinline__ void coop_count(const CoopItems<NI> &I, const float *w, float T, int (&first)[NI])
 {
+    int lo[NI], hi[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { lo[j] = I.base[j] + 1; hi[j] = I.a[j]; }
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const bool act = lo[j] < hi[j];
+            const int mid = (lo[j] + hi[j]) >> 1;
+            const bool f = I.sb[j] + w[mid & 63] <= T;
+            hi[j] = act && f ? mid : hi[j];
+            lo[j] = act && !f ? mid + 1 : lo[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) first[j] = hi[j];
+}
+
+// The next chunk of the workgroup: the same bound T in every wavefront, sized by the SUM of their counts (one barrier per
+// count), then the keys of (lo, T] into L.keys[0 .. n) -- wavefront v's behind those of the wavefronts before it, a lane's
+// behind those of the lanes before it -- and the cursors advanced.  Returns n, -1: cannot be split, 0: nothing left;
+// kbase / kcount: this wavefront's own keys (which it also scans: no barrier between the two).
+template <int NW, bool PROF>
+__device__ __forceinline__ int coop_next_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R, CoopItems<32 / NW> &I, float lo, int done,
+                                               int nall, int target, int lane, int wave, float &Tout, float &tprev, float &nprev, int &kbase, int &kcount,
+                                               PbcProf &Q)
+{
+    constexpr int NI = 32 / NW;
     const float inf = __builtin_inff();
     const float *w = L.one.w;
     const float m3 = (w[61] + w[62]) + w[63];
@@ -1686,40 +1649,38 @@ __device__ __forceinline__ int coop_next_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
     }
     if (!(T > lo)) T = lo > 0.0f ? lo * 1.05f : w[0];
     float tp = lo, np_ = (float)done;
-    int cnt = 0, c_ok = 0, tot_ok = 0, r = 0;      // cnt / c_ok: this wavefront's members; tot_ok: the workgroup's
-    bool anyover = false;
-    float T_ok = lo;
-    unsigned a_ok = ecur;
+    int first[NI], slot = 0, tot = 0;
+    float T_ok = lo;          // the largest bound counted so far that fits (tot_ok keys)
+    int tot_ok = 0;
+    bool last_ok = false;     // first / slot / tot describe T_ok
     for (int it = 0; it < 48; ++it) {
         PBC_STAMP(kPcWPick);
-        if constexpr (PROF) Q.pc[kPcWalks] += 1;
-        r = coop_walk<NW, PROF>(L, nxt, T, cnt, lane, wave, Q);
-        const int packed = coop_sum<NW>(R, r < 0 ? (1 << 24) : r);
+        PBC_COUNT(kPcWalks, 1);
+        coop_count<NI>(I, w, T, first);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) c += I.a[j] - first[j];
+        PBC_STAMP(kPcWDense);
+        slot = R.seq & 7;
+        {
+            const int cw = wave_add_i32(c);
+            tot = coop_sum<NW>(R, cw > kCoopWaveKeys ? cw + (1 << 24) : cw);     // (a wavefront scans its own keys: at most kCoopWaveKeys)
+        }
         PBC_STAMP(kPcWBarrier);
-        anyover = (packed >> 24) != 0;
-        const int tot = packed & 0xFFFFFF;
+        last_ok = false;
         bool over = false;
-        if (anyover) {
-            if (tot_ok > 0) break;
+        if (tot > kCoopCap) {
             over = true;
             Th = T;
-            L.cur[wave][lane] = ecur;                 // every wavefront back to the committed cursors
-            if (r > 0) coop_refresh<NW>(nxt, ecur, w, order, lane, wave);
-            cnt = 0;
-            if (wave == 0 && lane == 0) L.nkeys = 0;
-            __syncthreads();
+            if (tot_ok > 0 && it >= 3) break;        // (a usable smaller chunk is known: take it rather than search on)
+        } else if (tot > 0 && (!(T < inf) || 5 * tot >= 2 * target || it >= 3)) {
+            T_ok = T; tot_ok = tot; last_ok = true;
+            break;
+        } else if (!(T < inf)) {
+            return 0;                                // everything that can be visited has been
         } else {
-            cnt = r;
-            if (tot > 0 && (!(T < inf) || 5 * tot >= 2 * target || it >= 3)) {
-                c_ok = cnt; tot_ok = tot; T_ok = T;
-                a_ok = L.cur[wave][lane];
-                break;
-            } else if (!(T < inf)) {
-                return 0;
-            } else {
-                if (tot > 0) { c_ok = cnt; tot_ok = tot; T_ok = T; a_ok = L.cur[wave][lane]; }
-                Tl = T;
-            }
+            if (tot > 0) { T_ok = T; tot_ok = tot; last_ok = true; }
+            Tl = T;
         }
         float Tn;
         if (over) {
@@ -1738,28 +1699,71 @@ __device__ __forceinline__ int coop_next_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
         if (!(Tn > Tl) || !(Tn < Th)) break;
         T = Tn;
     }
-    if (tot_ok == 0) {
-        // (the last walk overflowed and was rolled back above, or every walk came back empty: the cursors are the committed ones)
-        return -1;
+    if (tot_ok == 0) return -1;
+    if (!last_ok) {     // the bound taken is not the one counted last: count it again (rare)
+        coop_count<NI>(I, w, T_ok, first);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) c += I.a[j] - first[j];
+        slot = R.seq & 7;
+        tot = coop_sum<NW>(R, wave_add_i32(c));
     }
-    if (anyover) {     // an overflow after a usable shorter chunk: back to that one (keys [0, tot_ok) are intact)
+    kbase = 0;
+#pragma unroll
+    for (int v = 0; v < NW; ++v) kbase += v < wave ? L.red[slot][v] : 0;
+    kcount = L.red[slot][wave];
+    // ---- the keys.  Offsets: wavefronts before mine (the counts just exchanged), lanes before mine, my items in turn.
+    int off = kbase;
+    int o[NI], cj[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        cj[j] = I.a[j] - first[j];
+        const int inc = wave_incl_add_dpp(cj[j]);
+        o[j] = off + inc - cj[j];
+        off += __builtin_amdgcn_readlane(inc, 63);
+    }
+    // Emission.  In a chunk ~26 of a wavefront's 128 items have members, ~6.5 each, at most ~15 (at 2.5 dB): a loop over the
+    // member number would run at a quarter of the lanes, a loop over the items at a tenth.  So the items with members leave
+    // a 16-byte descriptor in LDS (ballot + mbcnt), and every pass serves EIGHT of them, eight lanes each, a member per lane.
+    uint4 *const desc = L.desc[wave];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const u64 am = __ballot(cj[j] > 0);
+        const int na = __popcll(am);
+        if (cj[j] > 0)
+            desc[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u))] =
+                make_uint4((unsigned)I.a[j] | ((unsigned)cj[j] << 8) | ((unsigned)I.sh[j] << 16), (unsigned)o[j], __float_as_uint(I.sb[j]), I.code[j]);
         wave_fence();
-        L.cur[wave][lane] = a_ok;
-        if (r >= 0 && r != c_ok) coop_refresh<NW>(nxt, a_ok, w, order, lane, wave);
+        for (int p0 = 0; p0 < na; p0 += 8) {
+            const int it = p0 + (lane >> 3);
+            if (it < na) {
+                const uint4 d = desc[it];
+                const int a_ = (int)(d.x & 255u), c_ = (int)((d.x >> 8) & 255u), sh_ = (int)(d.x >> 16);
+                const float sb_ = __uint_as_float(d.z);
+                for (int k = lane & 7; k < c_; k += 8) {
+                    const int m = a_ - 1 - k;
+                    L.keys[(int)d.y + k] = ((u64)__float_as_uint(sb_ + w[m]) << 32) | (d.w | ((unsigned)m << sh_));
+                }
+            }
+        }
+        wave_fence();
     }
-    ecur = a_ok;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) I.a[j] = first[j];
+    PBC_STAMP(kPcWCollect);
     tprev = lo; nprev = (float)done;
     Tout = T_ok;
     return tot_ok;
 }
 
-// pbw_scan_chunk for the workgroup: wavefront v scans the 64-key slices v, v + NW, ... of the n keys; the reductions go
-// through LDS.  Returns 0 / 1 / -1 like pbw_scan_chunk, the same value in every wavefront; -1 leaves the state untouched.
+// pbw_scan_chunk for the workgroup: every wavefront scans the keys it generated (L.keys[kbase .. kbase + kcount)); the
+// reductions go through LDS.  Returns 0 / 1 / -1 like pbw_scan_chunk, the same value in every wavefront; -1 leaves the
+// state untouched.  The keys are not kept in registers: the ordinary chunk reads each once, the rare paths read them again.
 template <int NW, bool PROF>
-__device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R, const PbParams &P, const PbFrame &Fr, u64 d0, int n, float mn, float mx,
-                                               int lane, int wave, PbwState &S, int &stop, int &ntep, PbcProf &Q)
+__device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R, const PbParams &P, const PbFrame &Fr, u64 d0, int n, int kbase, int kcount,
+                                               float mn, float mx, int lane, int wave, PbwState &S, int &stop, int &ntep, PbcProf &Q)
 {
-    constexpr int CAP = kPbWaveCap, PER = kCoopCap / (64 * NW);
+    constexpr int CAP = kPbWaveCap, PER = kCoopWaveKeys / 64;
     const PbWaveLds<CAP> &T0 = L.one;
     if (S.nlive <= 1) return -1;
     const float best0 = S.best;
@@ -1780,128 +1784,171 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
         return D;
     };
     const auto sumbits = [](u64 key) { return (unsigned)(key >> 32); };
-    u64 kq[PER];
-    unsigned npneed = 0, npmask = 0, survmask = 0;
+    const auto key_at = [&](int k) { const int i = k * 64 + lane; return i < kcount ? L.keys[kbase + i] : ~0ull; };   // (an empty slot: all ones, sum NaN)
     int sumdel = 0, neg = 0, nsurv = 0;
-    unsigned short *const slist = reinterpret_cast<unsigned short *>(L.list[wave]);     // (the walk's list is idle now)
-#pragma unroll
-    for (int k = 0; k < PER; ++k) { const int i = (k * NW + wave) * 64 + lane; kq[k] = i < n ? L.keys[i] : ~0ull; }
+    unsigned fs = 0x7FFFFFFFu;     // the smallest sum on which rule 1 fires (against the chunk-start best)
+    unsigned short *const slist = L.slist[wave];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int i = (k * NW + wave) * 64 + lane;
-        const PbTep t = pbw_tep((unsigned)kq[k]);
-        const float rs = __uint_as_float((unsigned)(kq[k] >> 32));      // (an empty slot: NaN, every test below is false)
-        const bool surv = i < n && pbw_cost_floor<CAP>(T0, rs, parity(t)) < best0;
-        survmask |= surv ? 1u << k : 0u;
-        npneed |= rs > r_safe ? 1u << k : 0u;
-        const int dl = i < n ? pb_delta(t, P.order) : 0;
-        sumdel += dl; neg += dl < 0;
-    }
-    if (__ballot(survmask != 0)) {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const bool surv = (survmask >> k) & 1u;
+        if (k * 64 < kcount) {      // (uniform: a wavefront holds ~n / NW keys, four or five slices of the eight)
+            const u64 key = key_at(k);
+            const bool valid = k * 64 + lane < kcount;
+            const PbTep t = pbw_tep((unsigned)key);
+            const float rs = __uint_as_float(sumbits(key));
+            const bool surv = valid && pbw_cost_floor<CAP>(T0, rs, parity(t)) < best0;
             const u64 sm = __ballot(surv);
             if (sm) {
-                if (surv) slist[nsurv + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] = (unsigned short)((k * NW + wave) * 64 + lane);
+                if (surv) slist[nsurv + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] = (unsigned short)(kbase + k * 64 + lane);
                 nsurv += __popcll(sm);
+            }
+            const int dl = valid ? pb_delta(t, P.order) : 0;
+            sumdel += dl; neg += dl < 0;
+            const bool need = rs > r_safe;      // above the last safe probe (the last chunk of a search): the rule itself
+            if (__ballot(need)) {
+                float w1;
+                if (need && pb_not_promising(rs, best0, Fr, P.c4, T0.cdfA, T0.cdfH, w1) && sumbits(key) < fs) fs = sumbits(key);
             }
         }
     }
     PBC_STAMP(kPcSKeys);
-    if (wave == 0 && lane == 0) { L.ncand = 0; L.nrec = 0; L.stop2 = 0; L.tie0 = 0; }
-    // frontier growth and the pops that shrink it, over the whole chunk, in one exchange (per wavefront: |growth| <= 2 PER 64 < 2^12)
-    const int packed = coop_sum<NW>(R, (wave_add_i32(neg) << 18) + (wave_add_i32(sumdel) + 4096));
-    const int negtot = packed >> 18, deltot = (packed & 0x3FFFF) - NW * 4096;
-    PBC_STAMP(kPcSBar1);
-    if (S.nlive - negtot <= 1) return -1;
+    // One exchange settles the ordinary chunk.  (The OTHER candidate counter is reset here: it was last read before the barrier
+    // of this chunk's count; this chunk's was reset a chunk ago.)
+    const int par = R.par++ & 1;
+    if (wave == 0 && lane == 0) L.ncand[par ^ 1] = 0;
     // the survivors' exact costs; candidates (cost below the chunk-start best) go to the workgroup's list
     if (nsurv) {
+        // (a wavefront holds one or two survivors, rarely more: eight at a time, eight lanes each -- a lane sums one byte of the
+        //  discrepancy pattern in the canonical order (pbw_cost_exact), then the eight byte sums are added in order down the row)
         wave_fence();
-        for (int b0 = 0; b0 < nsurv; b0 += 64) {
-            const bool has = b0 + lane < nsurv;
-            const u64 key = has ? L.keys[slist[b0 + lane]] : 0ull;
-            const float c = has ? pbw_cost_exact<CAP>(T0, __uint_as_float((unsigned)(key >> 32)), parity(pbw_tep((unsigned)key))) : __builtin_inff();
+        for (int b0 = 0; b0 < nsurv; b0 += 8) {
+            const int sidx = b0 + (lane >> 3), byte = lane & 7;
+            const bool has = sidx < nsurv;
+            const u64 key = has ? L.keys[slist[has ? sidx : 0]] : 0ull;
+            const u64 D = parity(pbw_tep((unsigned)key));
+            const unsigned v = (unsigned)(D >> (8 * byte)) & 255u;
+            float bs = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) bs = ((v >> t) & 1u) ? bs + T0.w[64 + 8 * byte + t] : bs;
+            // acc_b = acc_(b-1) + bs_b, acc_(-1) = the key's sum: seven dependent steps, lane b takes lane b - 1's value (row_shr:1)
+            float acc = (byte == 0 ? __uint_as_float((unsigned)(key >> 32)) : 0.0f) + (byte == 0 ? bs : 0.0f);
+#pragma unroll
+            for (int st = 1; st < 8; ++st) {
+                const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111, 0xF, 0xF, true));
+                acc = byte == st ? prev + bs : acc;
+            }
+            const float c = has && byte == 7 ? acc : __builtin_inff();
             const bool cand = c < best0;
             const u64 cm = __ballot(cand);
             if (cm) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&L.ncand, __popcll(cm));
+                if (lane == 0) base = atomicAdd(&L.ncand[par], __popcll(cm));
                 base = __builtin_amdgcn_readfirstlane(base);
                 const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
                 if (cand && idx < kCoopMaxCand) { L.ck[idx] = key; L.cc[idx] = c; }
             }
         }
     }
-    if (__ballot(npneed != 0)) {      // rule 1 for the keys above the last safe probe (the last chunk of a search)
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const bool need = (npneed >> k) & 1u;
-            if (__ballot(need)) {
-                float w1;
-                if (need && pb_not_promising(__uint_as_float((unsigned)(kq[k] >> 32)), best0, Fr, P.c4, T0.cdfA, T0.cdfH, w1)) npmask |= 1u << k;
-            }
-        }
-    }
     PBC_STAMP(kPcSSurv);
-    __syncthreads();
+    // the exchange: frontier growth and the pops that shrink it (per wavefront |growth| <= 2 * 512 < 2^12), the smallest firing sum
+    int negtot, deltot;
+    unsigned sF;
+    {
+        const int slot = R.seq++ & 7;
+        const int x1 = (wave_add_i32(neg) << 18) + (wave_add_i32(sumdel) + 4096), x2 = wave_min_i32((int)fs);
+        if (lane == 0) { L.red[slot][wave] = x1; L.red2[slot][wave] = x2; }
+        __syncthreads();
+        int a = 0, m = 0x7FFFFFFF;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) { a += L.red[slot][v]; const int x = L.red2[slot][v]; m = x < m ? x : m; }
+        negtot = a >> 18; deltot = (a & 0x3FFFF) - NW * 4096; sF = (unsigned)m;
+    }
     PBC_STAMP(kPcSBar2);
-    const int ncand = L.ncand;
+    const int ncand = L.ncand[par];
+    if (S.nlive - negtot <= 1) return -1;
     if (ncand > kCoopMaxCand) return -1;
+    if (ncand == 0) {
+        if (sF == 0x7FFFFFFFu) {     // no candidate, no key fires: the whole chunk is visited and nothing else happens
+            S.cmp += 2 * n; S.suc1 += n;
+            S.j += n; S.nlive += deltot;
+            return 0;
+        }
+        // no candidate, rule 1 fires: the search stops at the first key of the smallest firing sum (every key of that sum fires)
+        int cs = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (k * 64 < kcount) cs += sumbits(key_at(k)) < sF;
+        const int rank_stop = coop_sum<NW>(R, wave_add_i32(cs));
+        PBC_STAMP(kPcSPos);
+        S.cmp += 2 * (rank_stop + 1);
+        S.suc1 += rank_stop;
+        stop = 1; ntep = S.j + rank_stop + 1;
+        return 1;
+    }
+    // ---- candidates: wavefront 0 orders them and finds the records; the others wait
     bool tie = false;
-    if (ncand > 0) {   // (the same in every wavefront) wavefront 0 orders the candidates and finds the records; the others wait
-        if (wave == 0) {
-            const u64 my = lane < ncand ? L.ck[lane] : ~0ull;
-            const float myc = lane < ncand ? L.cc[lane] : 0.0f;
-            int rk0 = 0;
-            bool t0 = false;
-            for (int d = 0; d < ncand; ++d) { const u64 o = L.ck[d]; rk0 += sumbits(o) < sumbits(my); t0 |= lane < ncand && sumbits(o) == sumbits(my) && o != my; }
-            wave_fence();
-            if (lane < ncand) { L.ck[rk0] = my; L.cc[rk0] = myc; }
-            wave_fence();
-            int nrec = 0, stop2 = 0;
-            if (!__ballot(t0)) {
-                float before = best0;
-                for (int t = 0; t < ncand && !stop2; ++t) {
-                    const u64 key = L.ck[t];
-                    const float c = L.cc[t];
-                    if (c < before) {
-                        if (lane == 0) { L.rk[nrec] = key; L.rc[nrec] = c; }
-                        ++nrec;
-                        const float w1 = det_expf(P.c4 * __uint_as_float((unsigned)(key >> 32))) * Fr.spl;
-                        if (pb_success(parity(pbw_tep((unsigned)key)), w1, T0.tq, Fr)) stop2 = 1;
-                        before = c;
-                    }
+    if (wave == 0) {
+        const u64 my = lane < ncand ? L.ck[lane] : ~0ull;
+        const float myc = lane < ncand ? L.cc[lane] : 0.0f;
+        int rk0 = 0;
+        bool t0 = false;
+        for (int d = 0; d < ncand; ++d) { const u64 o = L.ck[d]; rk0 += sumbits(o) < sumbits(my); t0 |= lane < ncand && sumbits(o) == sumbits(my) && o != my; }
+        wave_fence();
+        if (lane < ncand) { L.ck[rk0] = my; L.cc[rk0] = myc; }
+        wave_fence();
+        int nrec = 0, stop2 = 0;
+        if (!__ballot(t0)) {
+            float before = best0;
+            for (int t = 0; t < ncand && !stop2; ++t) {
+                const u64 key = L.ck[t];
+                const float c = L.cc[t];
+                if (c < before) {
+                    if (lane == 0) { L.rk[nrec] = key; L.rc[nrec] = c; }
+                    ++nrec;
+                    const float w1 = det_expf(P.c4 * __uint_as_float((unsigned)(key >> 32))) * Fr.spl;
+                    if (pb_success(parity(pbw_tep((unsigned)key)), w1, T0.tq, Fr)) stop2 = 1;
+                    before = c;
                 }
             }
-            if (lane == 0) { L.nrec = nrec; L.stop2 = stop2; L.tie0 = __ballot(t0) ? 1 : 0; }
         }
-        __syncthreads();
+        if (lane == 0) { L.nrec = nrec; L.stop2 = stop2; L.tie0 = __ballot(t0) ? 1 : 0; }
     }
+    __syncthreads();
     const int nrec = L.nrec, stop2 = L.stop2;
     tie |= L.tie0 != 0;
-    if (nrec > 0) {    // rule 1 again for the keys behind the first record, with the best they see
-        const u64 r0k = L.rk[0];
-        const unsigned s0 = sumbits(r0k);
-#pragma unroll
+    // Rule 1 again for the keys from the first record on, each with the best it really sees (the record before it).  A lower
+    // best fires sooner (beta falls with it), so a key that the LAST record's cost does not stop is stopped by none: probes
+    // with that cost (as above) leave the keys beyond the last safe probe to evaluate -- usually none.  Keys before the first
+    // record keep what the chunk-start best said (fs, if it lies before the first record).
+    if (nrec > 0) {
+        const unsigned s0 = sumbits(L.rk[0]);
+        float r_safe2;
+        {
+            const float rp = lane == 63 ? mx : mn + (mx - mn) * ((float)(lane + 1) * (1.0f / 64.0f));
+            float w1;
+            const float bs = pb_promising_bs(rp, L.rc[nrec - 1], Fr, P.c4, T0.cdfA, T0.cdfH, w1);
+            const u64 unsafe = ~__ballot((double)bs > Fr.p_t_pro * 1.001);
+            const int u = unsafe ? __builtin_ctzll(unsafe) : 64;
+            r_safe2 = u == 0 ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rp), u - 1));
+        }
+        fs = fs < s0 ? fs : 0x7FFFFFFFu;
+#pragma unroll 1
         for (int k = 0; k < PER; ++k) {
-            if (kq[k] != ~0ull && sumbits(kq[k]) >= s0 && kq[k] != r0k) {
+            if (k * 64 < kcount) {
+                const u64 key = key_at(k);
+                const bool behind = key != ~0ull && sumbits(key) >= s0;
                 int t = 0;
-                for (int u = 0; u < nrec; ++u) { const u64 r = L.rk[u]; t += sumbits(r) < sumbits(kq[k]); tie |= sumbits(r) == sumbits(kq[k]) && r != kq[k]; }
-                if (t > 0) {
-                    float w1;
-                    const bool np = pb_not_promising(__uint_as_float(sumbits(kq[k])), L.rc[t - 1], Fr, P.c4, T0.cdfA, T0.cdfH, w1);
-                    npmask = (npmask & ~(1u << k)) | (np ? 1u << k : 0u);
+                if (behind)
+                    for (int u = 0; u < nrec; ++u) { const u64 r = L.rk[u]; t += sumbits(r) < sumbits(key); tie |= sumbits(r) == sumbits(key) && r != key; }
+                const bool need = behind && __uint_as_float(sumbits(key)) > r_safe2;
+                if (__ballot(need)) {
+                    float w1;      // (the first record itself is judged with the chunk-start best: t = 0)
+                    if (need && pb_not_promising(__uint_as_float(sumbits(key)), t > 0 ? L.rc[t - 1] : best0, Fr, P.c4, T0.cdfA, T0.cdfH, w1) && sumbits(key) < fs) fs = sumbits(key);
                 }
             }
         }
     }
     PBC_STAMP(kPcSCand);
-    unsigned fs = 0x7FFFFFFFu;     // the smallest sum on which rule 1 fires
-#pragma unroll
-    for (int k = 0; k < PER; ++k)
-        if (((npmask >> k) & 1u) && sumbits(kq[k]) < fs) fs = sumbits(kq[k]);
-    const unsigned sF = (unsigned)coop_min<NW>(R, wave_min_i32((int)fs));
+    sF = (unsigned)coop_min<NW>(R, wave_min_i32((int)fs));
     PBC_STAMP(kPcSMin);
     int reason = 0;
     unsigned sstop = 0;
@@ -1917,18 +1964,20 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
         for (int u = 0; u < nrec; ++u) nbefore += sumbits(L.rk[u]) < sstop;
         nbefore += reason == 2;
     }
-    // positions: the keys below the last record that counts, the keys below the stopping sum; ties (one exchange: 12 + 12 + 1 bits)
+    // positions: the keys below the last record that counts, the keys below the stopping sum; ties (one exchange: 13 + 13 + 1 bits)
     const u64 bk = nbefore > 0 ? L.rk[nbefore - 1] : 0ull;
     const float bcost = nbefore > 0 ? L.rc[nbefore - 1] : 0.0f;
     int cb = 0, cs = 0;
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < PER; ++k) {
-        if (nbefore > 0) { cb += sumbits(kq[k]) < sumbits(bk); tie |= sumbits(kq[k]) == sumbits(bk) && kq[k] != bk; }
-        if (reason == 1) cs += sumbits(kq[k]) < sstop;
+        if (k * 64 < kcount) {
+            const u64 key = key_at(k);
+            if (nbefore > 0) { cb += sumbits(key) < sumbits(bk); tie |= sumbits(key) == sumbits(bk) && key != bk; }
+            if (reason == 1) cs += sumbits(key) < sstop;
+        }
     }
     const int pos = coop_sum<NW>(R, wave_add_i32(cb) + (wave_add_i32(cs) << 13) + (__ballot(tie) ? 1 << 26 : 0));
-    if (wave == 0 && lane == 0) L.nkeys = 0;          // (the next chunk's buffer starts empty)
-    __syncthreads();                                  // (and the candidate / record words are free again)
+    __syncthreads();                                  // (the candidate / record words are free again)
     PBC_STAMP(kPcSPos);
     if (pos >> 26) return -1;
     const int rank_best = pos & 0x1FFF, rank_stop = reason == 2 ? rank_best : (pos >> 13) & 0x1FFF;
@@ -2002,7 +2051,7 @@ __device__ __noinline__ void coop_solo_range(PbCoopLds<NW> &L)
         done += n;
     }
     wave_fence();
-    if (lane == 0) { L.bs = S; L.bstate = state; L.bstop = stop; L.bntep = ntep; L.nkeys = 0; }
+    if (lane == 0) { L.bs = S; L.bstate = state; L.bstop = stop; L.bntep = ntep; }
 }
 
 template <int NW, bool PROF>
@@ -2013,7 +2062,9 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
     //  registered once in pb_ctx_init)
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_coop_lds[];
     PbcProf Q;
-    if constexpr (PROF) { for (int k = 0; k < kPcSlots; ++k) Q.pc[k] = 0; Q.last = __builtin_amdgcn_s_memtime(); }
+    PbCoopLds<NW> &L0 = *reinterpret_cast<PbCoopLds<NW> *>(pb_coop_lds);
+    Q.pc = L0.prof;
+    if constexpr (PROF) { if (threadIdx.x == 0) for (int k = 0; k < kPcSlots; ++k) Q.pc[k] = 0; Q.last = __builtin_amdgcn_s_memtime(); }
     PbCoopLds<NW> &L = *reinterpret_cast<PbCoopLds<NW> *>(pb_coop_lds);
     constexpr int NI = 32 / NW;
     static_assert(64 * NW >= 64 + kPbRecPrefix, "wavefronts 1.. copy a record's tables in one go");
@@ -2026,14 +2077,15 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
         L.one.cdfH[lane] = (float)cdf_half[lane];
         if (lane == 0) { L.one.cdfH[64] = (float)cdf_half[64]; L.ticket[0] = atomicAdd(&ctl[kPbCtlTicketC], 1); L.sP = P; }
     }
-    CoopRed<NW> R{L.red, 0, wave, lane};
+    CoopRed<NW> R{L.red, 0, wave, lane, 0};
     __syncthreads();
     for (int it = 0;; ++it) {
         // frames are handed out by ticket; the NEXT frame's ticket is drawn now and is back long before it is needed
         int tk = L.ticket[it & 1];
         if (tk >= nlist) break;
-        if (tid == 0) { L.ticket[(it + 1) & 1] = atomicAdd(&ctl[kPbCtlTicketC], 1); L.nkeys = 0; }
-        const unsigned *rec = carry + (long long)tk * kPbRecWords;
+        if (tid == 0) { L.ticket[(it + 1) & 1] = atomicAdd(&ctl[kPbCtlTicketC], 1); L.ncand[0] = 0; L.ncand[1] = 0; }
+        // (records are taken last-in first-out: the searches handed over late started late or ran long in the chunk kernel)
+        const unsigned *rec = carry + (long long)(P.coop_lifo ? nlist - 1 - tk : tk) * kPbRecWords;
         // the frame's tables: one load per thread (wavefront 0 may still be writing the previous frame's codeword out)
         if (tid >= 64 && tid < 64 + kPbRecPrefix) reinterpret_cast<unsigned *>(&L.one)[tid - 64] = rec[tid - 64];
         const PbCarry &c = *reinterpret_cast<const PbCarry *>(rec + kPbRecScalars);
@@ -2044,61 +2096,65 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
         S.bestD = c.bestD; S.bestE = c.bestE;
         float lo = c.lo;
         int done = S.j;
-        unsigned ecur = 0;
+        int a0[NI];            // the cursors the record holds
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             int q, l;
             coop_item<NW>(wave, j, lane, q, l);
-            ecur |= ((rec[kPbRecCur + (q >> 2) * 64 + l] >> (8 * (q & 3))) & 255u) << (8 * j);
+            a0[j] = (int)((rec[kPbRecCur + (q >> 2) * 64 + l] >> (8 * (q & 3))) & 255u);
         }
-        L.cur[wave][lane] = ecur;
         __syncthreads();
-        float nxt[NI];
-        coop_refresh<NW>(nxt, ecur, L.one.w, P.order, lane, wave);
+        CoopItems<NI> I;
+        coop_items_init<NW>(I, L.one.w, P.order, lane, wave);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) I.a[j] = a0[j];
         float smax = P.order > 2 ? (L.one.w[0] + L.one.w[1]) + L.one.w[2] : (P.order > 1 ? L.one.w[0] + L.one.w[1] : L.one.w[0]);
         int stop = 0, ntep = P.nmax, state = 0;
         float tprev = 0.0f, nprev = 0.0f;
         PBC_STAMP(kPcSetup);
         while (state == 0 && done < nall) {
-            const unsigned eprev = ecur;
+            int aprev[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) aprev[j] = I.a[j];
             float T;
-            int n = coop_next_chunk<NW, PROF>(L, R, nxt, ecur, P.order, lo, done, nall, P.t3, lane, wave, T, tprev, nprev, Q);
+            int kbase = 0, kcount = 0;
+            int n = coop_next_chunk<NW, PROF>(L, R, I, lo, done, nall, P.t3, lane, wave, T, tprev, nprev, kbase, kcount, Q);
             PBC_STAMP(kPcWalk);
             if (n < 0) { state = 2; break; }
             if (n == 0) break;
-            if constexpr (PROF) { Q.pc[kPcChunks] += 1; Q.pc[kPcKeys] += n; }
+            PBC_COUNT(kPcChunks, 1); PBC_COUNT(kPcKeys, n);
             const float cmn = lo < 0.0f ? L.one.w[63] : lo, cmx = T < __builtin_inff() ? T : smax;
-            state = coop_scan_chunk<NW, PROF>(L, R, P, Fr, d0, n, cmn, cmx, lane, wave, S, stop, ntep, Q);
+            wave_fence();
+            state = coop_scan_chunk<NW, PROF>(L, R, P, Fr, d0, n, kbase, kcount, cmn, cmx, lane, wave, S, stop, ntep, Q);
             PBC_STAMP(kPcScan);
             if (state < 0) {
-                if constexpr (PROF) { Q.pc[kPcSolos] += 1; Q.pc[kPcSoloKeys] += n; }
+                PBC_COUNT(kPcSolos, 1); PBC_COUNT(kPcSoloKeys, n);
                 // wavefront 0 redoes the chunk alone from the cursors the chunk started with
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     int q, l;
                     coop_item<NW>(wave, j, lane, q, l);
-                    reinterpret_cast<unsigned char *>(&L.one.cur[q >> 2][l])[q & 3] = (unsigned char)((eprev >> (8 * j)) & 255u);
+                    reinterpret_cast<unsigned char *>(&L.one.cur[q >> 2][l])[q & 3] = (unsigned char)aprev[j];
                 }
                 __syncthreads();
                 if (wave == 0) {
                     // (everything this wavefront needs afterwards is parked in LDS around the call: see PbCoopLds::sv)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) L.sv[j][lane] = nxt[j];
-                    L.sv[NI][lane] = __uint_as_float(ecur);
+                    for (int j = 0; j < NI; ++j) L.sv[j][lane] = I.a[j];
                     if (lane == 0) {
                         L.su.fr = Fr; L.su.d0 = d0; L.su.lo = lo; L.su.T = T; L.su.tprev = tprev; L.su.nprev = nprev; L.su.smax = smax;
-                        L.su.done = done; L.su.n = n; L.su.seq = R.seq; L.su.it = it; L.su.tk = tk;
+                        L.su.done = done; L.su.n = n; L.su.seq = R.seq; L.su.par = R.par; L.su.it = it; L.su.tk = tk;
                         L.bs = S; L.bstop = stop; L.bntep = ntep;
                     }
                     wave_fence();
                     coop_solo_range<NW>(L);
                     wave_fence();
+                    coop_items_init<NW>(I, L.one.w, P.order, lane, wave);
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) nxt[j] = L.sv[j][lane];
-                    ecur = __float_as_uint(L.sv[NI][lane]);
+                    for (int j = 0; j < NI; ++j) I.a[j] = L.sv[j][lane];
                     Fr = L.su.fr; d0 = L.su.d0; lo = L.su.lo; T = L.su.T; tprev = L.su.tprev; nprev = L.su.nprev; smax = L.su.smax;
-                    done = L.su.done; n = L.su.n; R.seq = L.su.seq; it = L.su.it; tk = L.su.tk;
-                    rec = carry + (long long)tk * kPbRecWords;
+                    done = L.su.done; n = L.su.n; R.seq = L.su.seq; R.par = L.su.par; it = L.su.it; tk = L.su.tk;
+                    rec = carry + (long long)(P.coop_lifo ? nlist - 1 - tk : tk) * kPbRecWords;
                 }
                 __syncthreads();
                 S = L.bs; state = L.bstate; stop = L.bstop; ntep = L.bntep;
@@ -2133,7 +2189,7 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
             }
         }
         PBC_STAMP(kPcOut);
-        if constexpr (PROF) Q.pc[kPcFrames] += 1;
+        PBC_COUNT(kPcFrames, 1);
     }
     if constexpr (PROF) { if (tid == 0 && Q.pc[kPcFrames]) for (int k = 0; k < kPcSlots; ++k) atomicAdd(&prof_out[k], Q.pc[k]); }
 }
@@ -2421,6 +2477,8 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     if (const char *e = getenv("LDPC_PB_BUDGET_S")) pp.budget_s = atoi(e);
     if (const char *e = getenv("LDPC_PB_BUDGET_M")) pp.budget_m = atoi(e);
     if (const char *e = getenv("LDPC_PB_T3")) pp.t3 = atoi(e);
+    pp.coop_lifo = 1;
+    if (const char *e = getenv("LDPC_PB_LIFO")) pp.coop_lifo = atoi(e);
     if (const char *e = getenv("LDPC_PB_T2")) pp.t2 = atoi(e);
     if (const char *e = getenv("LDPC_PB_T1")) pp.t1 = atoi(e);
    // chunk targets: the first chunk's count is only guessed (+-40 %), the others follow the growth of the counts
