@@ -82,6 +82,7 @@ struct PbParams {
     int t1, t2;                  // chunk targets: first chunk / later chunks
     int t3, budget;              // chunk target of the workgroup kernel; TEPs after which a frame may be handed to it
     int budget_s, budget_m;      // ... when its sub-list is short (< 128 frames) / of medium length (< 448)
+    int budget_l, budget_xl;     // ... long (1400 .. 3000) / very long
     int coop_lifo;
     int handoff_maxlen;          // ... if its sub-list of list A holds fewer frames than this (many searches: throughput counts, none leaves)
     float c4;
@@ -1301,7 +1302,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
     const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);      // TEPs of weight 1..order
     // TEPs after which a search may leave for the latency-shaped kernel: the fewer frames search, the sooner (a lone wavefront
     // takes ~30 us per chunk; measured per step at 3.5 / 3.0 dB: 0.25 / 0.43 ms with 512, 0.27 / 0.41 with 1024, 0.36 / 0.49 with 4096)
-    const int budget = len < 128 ? P.budget_s : (len < 448 ? P.budget_m : P.budget);
+    const int budget = len < 128 ? P.budget_s : (len < 448 ? P.budget_m : (len < 1400 ? P.budget : (len < 3000 ? P.budget_l : P.budget_xl)));
     bool have_cdfh = false;
     for (int k = blockIdx.x >> 4; k < len; k += gridDim.x >> 4) {
         if (!have_cdfh) {
@@ -2466,16 +2467,25 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     pp.order = p->order; pp.nmax = (int)nmax; pp.cmin_off = spill_slots;
     pp.t3 = 3072; pp.budget = 4096;
     pp.t1 = 320; pp.t2 = kPbWaveCap * 13 / 16;
-    // hand long searches on only when few frames search at all (each of the 16 sub-lists of list A shorter than 1024: from
-    // ~2.25 dB up).  Measured, PB kernels per 131 072-frame step with / without the hand-over: 3.5 dB 0.36 / 0.50 ms, 3.0 dB
-    // 0.49 / 0.81, 2.5 dB 0.88 / 1.14 -- 2.0 dB 2.27 / 1.95, 1.5 dB 4.00 / 3.70, 1.0 dB 7.47 / 7.06: with many searches the
-    // chunk kernel's throughput is what counts and the 1024-thread launch only adds its own time.
-    pp.handoff_maxlen = 1024;
+    // When a search leaves the chunk kernel for the workgroup kernel: after `budget` TEPs, the budget chosen ON THE DEVICE from the
+    // length of the frame's sub-list of list A (a sixteenth of the frames that search beyond the weight-1 head), so that the
+    // workgroup kernel gets the tails, 1000-3500 frames a call, and never the bulk (its list holds kPbHeavyCap frames).
+    // Measured per 131 072-frame step, PB kernels with the budget of the schedule / the neighbouring ones / no hand-over:
+    //   3.5 dB (length 42)    512: 0.20 ms              2.0 dB  (1750)   8192: 1.50 | 4096: 1.52 | 16384: 1.61 | none 1.80
+    //   3.0 dB (177)         1024: 0.34                 1.75 dB (2560)   8192: 2.20 | 16384: 2.26 | 4096: 2.91 | none 2.50
+    //   2.5 dB (626)         4096: 0.70 | 2048: 0.70    1.5 dB  (3475)  16384: 3.22 | 8192: 3.78 | none 3.41
+    //   2.25 dB (1090)       4096: 1.02 | none 1.45     1.0 dB  (5300)  16384: 6.26 | 8192: 6.85 | none 6.44
+    // (serial kernel sums; with four batches in flight -- bench.py's graph -- 24576 beats 16384 and none at 1.0 dB: 2.15 / 2.12 / 2.14 x 10^7
+    //  frames/s, and ties with 16384 at 1.5 dB: 4.25 x 10^7 against 4.18 without)
+    pp.handoff_maxlen = 1 << 30;
     if (const char *e = getenv("LDPC_PB_HANDOFF_MAXLEN")) pp.handoff_maxlen = atoi(e);
     pp.budget_s = pp.budget / 8; pp.budget_m = pp.budget / 4;
     if (const char *e = getenv("LDPC_PB_BUDGET")) pp.budget = atoi(e);   // (tuning aids)
     if (const char *e = getenv("LDPC_PB_BUDGET_S")) pp.budget_s = atoi(e);
     if (const char *e = getenv("LDPC_PB_BUDGET_M")) pp.budget_m = atoi(e);
+    pp.budget_l = 2 * pp.budget; pp.budget_xl = 6 * pp.budget;
+    if (const char *e = getenv("LDPC_PB_BUDGET_L")) pp.budget_l = atoi(e);
+    if (const char *e = getenv("LDPC_PB_BUDGET_XL")) pp.budget_xl = atoi(e);
     if (const char *e = getenv("LDPC_PB_T3")) pp.t3 = atoi(e);
     pp.coop_lifo = 1;
     if (const char *e = getenv("LDPC_PB_LIFO")) pp.coop_lifo = atoi(e);
