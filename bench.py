@@ -497,7 +497,7 @@ def run_rank(args):
             f_per_step = c[5] / (args.steps * world)
             if tm[:, 1].mean() > 0.02:   # two-kernel OSD (front end + search through the workspace)
                 kern["osd_front_kernel"] = (float(tm[:, 1].mean()), (512 + 640) * f_per_step)
-                sname = {1: "osd_fs_kernel", 2: "pb_osd (singles + chunk + latency-shaped kernels)"}.get(algo, "osd_search2r_kernel" if order == 2 else "osd_search_kernel")
+                sname = {1: "osd_fs_kernel", 2: "pb_osd (singles + chunk + workgroup kernels)"}.get(algo, "osd_search2r_kernel" if order == 2 else "osd_search_kernel")
                 kern[sname] = (float(tm[:, 2].mean()), (1152 + 24) * f_per_step)
             else:                        # OSD through the context workspace: one combined duration
                 kern["osd_front+search"] = (float(tm[:, 2].mean()), OSD_BYTES_PER_FRAME * f_per_step)

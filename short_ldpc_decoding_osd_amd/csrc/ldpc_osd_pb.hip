@@ -23,10 +23,13 @@
 //                      while |y'_p| < |y'_62| + |y'_63| (the smallest weight-2 sum); one TEP per lane.  Two thirds
 //                      of the frames stop here at 2.5 dB; the others are appended to list A.
 //   pb_wave_kernel     one frame of list A per WAVEFRONT (round 3; rounds 1-2 used 256- and 1024-thread workgroups),
-//                      restarted from its first TEP and taken to its stop: chunks of <= 512 TEPs, each = the members of a
-//                      sum range walked directly from the sorted reliabilities (no table, no binary searches); bucket
-//                      rank sort in LDS; exact tie repair; parallel evaluation; sequential rules by prefix scans.  No
-//                      workgroup barrier anywhere.  Massive ties go to list B.
+//                      continued from the head: chunks of <= 512 TEPs, each = the members of a sum range walked directly
+//                      from the sorted reliabilities, judged by a sort-free pass (sorted only when that cannot settle the
+//                      chunk).  No workgroup barrier anywhere.  Massive ties go to list B; a search that passes a budget
+//                      of TEPs (chosen on the device from the number of searching frames) leaves with its state.
+//   pb_coop_kernel     those long searches, one frame per 16-wavefront WORKGROUP: chunks of <= 4096 TEPs counted by
+//                      bisection and generated once, every wavefront judging the keys it generated; one workgroup
+//                      barrier per count and one per ordinary chunk.
 //   pb_seq_kernel      the literal list replay (round-1 kernel) for list B.
 #include <math.h>
 #include <stdio.h>
@@ -1300,8 +1303,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
     const int sub = blockIdx.x & (kPbSub - 1);
     const int len = ctl[kPbCtlLenA + kPbCtlLine * sub];
     const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);      // TEPs of weight 1..order
-    // TEPs after which a search may leave for the latency-shaped kernel: the fewer frames search, the sooner (a lone wavefront
-    // takes ~30 us per chunk; measured per step at 3.5 / 3.0 dB: 0.25 / 0.43 ms with 512, 0.27 / 0.41 with 1024, 0.36 / 0.49 with 4096)
+    // TEPs after which a search may leave for the workgroup kernel: the fewer frames search, the sooner (a lone wavefront
+    // takes ~30 us per chunk of ~400 TEPs, the workgroup ~12 us per chunk of ~2700; the schedule and its measurements: launch_pb)
     const int budget = len < 128 ? P.budget_s : (len < 448 ? P.budget_m : (len < 1400 ? P.budget : (len < 3000 ? P.budget_l : P.budget_xl)));
     bool have_cdfh = false;
     for (int k = blockIdx.x >> 4; k < len; k += gridDim.x >> 4) {
@@ -1384,7 +1387,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
         }
         PBW_STAMP(kPwSetup);
         const float smax = P.order > 2 ? (L.w[0] + L.w[1]) + L.w[2] : (P.order > 1 ? L.w[0] + L.w[1] : L.w[0]);
-        int stop = 0, ntep = P.nmax, state = 0;   // state: 0 = searching, 1 = a rule fired, 2 = to the list replay, 3 = to the latency-shaped kernel
+        int stop = 0, ntep = P.nmax, state = 0;   // state: 0 = searching, 1 = a rule fired, 2 = to the list replay, 3 = to the workgroup kernel
         bool asked = false;
         float tprev = 0.0f, nprev = 0.0f;
         while (state == 0 && done < nall) {
@@ -1406,7 +1409,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
             lo = T;
             done += n;
             if (state == 0 && done >= budget && !asked && done < nall && len < P.handoff_maxlen) {
-                // a long search: the latency-shaped kernel takes it over if it still has room (at most kPbHeavyCap frames a call)
+                // a long search: the workgroup kernel takes it over if it still has room (at most kPbHeavyCap frames a call)
                 asked = true;
                 int slot = 0;
                 if (lane == 0) slot = atomicAdd(&ctl[kPbCtlLenC], 1);

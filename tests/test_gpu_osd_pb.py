@@ -113,3 +113,31 @@ def test_pb_other_input_scalings(dec, scale):
     ref = _check(dec, y, cw, 3, snr, None)
     assert ref["num_teps"].max() > 1000
     _check(dec, y, cw, 3, snr, "block", ref)
+
+
+def test_pb_workgroup_kernel_overflowing_hand_over(dec, monkeypatch):
+    """The workgroup kernel takes at most 4096 searches a call: with the hand-over budget forced to 64 TEPs (tuning
+    variables of launch_pb) more than that ask to leave the chunk kernel -- the first 4096 are finished by the workgroup
+    kernel from their first chunks on, the others stay where they are.  Same counts, stops, winners and metrics."""
+    for v in ("LDPC_PB_BUDGET_S", "LDPC_PB_BUDGET_M", "LDPC_PB_BUDGET", "LDPC_PB_BUDGET_L", "LDPC_PB_BUDGET_XL"):
+        monkeypatch.setenv(v, "64")
+    y, cw = _failures(dec, 1.5, 14000, seed=5)
+    y, cw = y[:8000], cw[:8000]
+    assert y.shape[0] == 8000
+    ref = _check(dec, y, cw, 3, 1.5, None)
+    assert (ref["num_teps"] > 64).sum() > 4096 + 200
+
+
+@pytest.mark.parametrize("quant", [1024.0, 16384.0])
+def test_pb_workgroup_kernel_ties(dec, quant, monkeypatch):
+    """Long searches on finely quantised channel values: equal sums deep inside a search, where the workgroup kernel's
+    sort-free pass meets a tie against a reference key and wavefront 0 redoes the chunk with the sorted path."""
+    monkeypatch.setenv("LDPC_PB_BUDGET_S", "128")
+    rng = np.random.default_rng(int(quant) + 1)
+    y, cw = np_oracle.make_frames(dec.code.G, 1.0, 400, rng)
+    y = (np.round(y * quant) / quant).astype(np.float32)
+    soft = c_oracle.nms(dec.code.H, y, 10, ALPHA0)
+    _, fail, _ = c_oracle.evaluate(dec.code.H, soft, cw)
+    idx = np.flatnonzero(fail)[:96]
+    ref = _check(dec, y[idx], cw[idx], 3, 1.0, None)
+    assert ref["num_teps"].max() > 8000
