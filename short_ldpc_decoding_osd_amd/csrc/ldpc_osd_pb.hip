@@ -1503,7 +1503,7 @@ struct __attribute__((aligned(16))) PbCoopLds {
         PbFrame fr;
         u64 d0;
         float lo, T, tprev, nprev, smax;
-        int done, n, seq, par, it, tk;
+        int done, n, seq, par, it, tk, next_tk;
     } su;
     PbParams sP;
     unsigned long long prof[32];      // diagnostic build only
@@ -2087,12 +2087,14 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
         // frames are handed out by ticket; the NEXT frame's ticket is drawn now and is back long before it is needed
         int tk = L.ticket[it & 1];
         if (tk >= nlist) break;
-        if (tid == 0) { L.ticket[(it + 1) & 1] = atomicAdd(&ctl[kPbCtlTicketC], 1); L.ncand[0] = 0; L.ncand[1] = 0; }
+        int next_tk = 0;      // (drawn now, parked in LDS at the frame's end: the wavefront does not wait for the atomic here)
+        if (tid == 0) { next_tk = atomicAdd(&ctl[kPbCtlTicketC], 1); L.ncand[0] = 0; L.ncand[1] = 0; }
         // (records are taken last-in first-out: the searches handed over late started late or ran long in the chunk kernel)
         const unsigned *rec = carry + (long long)(P.coop_lifo ? nlist - 1 - tk : tk) * kPbRecWords;
         // the frame's tables: one load per thread (wavefront 0 may still be writing the previous frame's codeword out)
         if (tid >= 64 && tid < 64 + kPbRecPrefix) reinterpret_cast<unsigned *>(&L.one)[tid - 64] = rec[tid - 64];
         const PbCarry &c = *reinterpret_cast<const PbCarry *>(rec + kPbRecScalars);
+        unsigned po = wave == 0 ? rec[kPbRecPerm + lane] : 0u;      // (the permutation, for the codeword at the end: in flight from here)
         PbFrame Fr = c.fr;
         u64 d0 = c.d0;
         PbwState S;
@@ -2147,7 +2149,7 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
                     for (int j = 0; j < NI; ++j) L.sv[j][lane] = I.a[j];
                     if (lane == 0) {
                         L.su.fr = Fr; L.su.d0 = d0; L.su.lo = lo; L.su.T = T; L.su.tprev = tprev; L.su.nprev = nprev; L.su.smax = smax;
-                        L.su.done = done; L.su.n = n; L.su.seq = R.seq; L.su.par = R.par; L.su.it = it; L.su.tk = tk;
+                        L.su.done = done; L.su.n = n; L.su.seq = R.seq; L.su.par = R.par; L.su.it = it; L.su.tk = tk; L.su.next_tk = next_tk;
                         L.bs = S; L.bstop = stop; L.bntep = ntep;
                     }
                     wave_fence();
@@ -2159,6 +2161,8 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
                     Fr = L.su.fr; d0 = L.su.d0; lo = L.su.lo; T = L.su.T; tprev = L.su.tprev; nprev = L.su.nprev; smax = L.su.smax;
                     done = L.su.done; n = L.su.n; R.seq = L.su.seq; R.par = L.su.par; it = L.su.it; tk = L.su.tk;
                     rec = carry + (long long)(P.coop_lifo ? nlist - 1 - tk : tk) * kPbRecWords;
+                    po = rec[kPbRecPerm + lane];
+                    next_tk = L.su.next_tk;
                 }
                 __syncthreads();
                 S = L.bs; state = L.bstate; stop = L.bstop; ntep = L.bntep;
@@ -2167,6 +2171,7 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
             lo = T;
             done += n;
         }
+        if (tid == 0) L.ticket[(it + 1) & 1] = next_tk;
         __syncthreads();                        // (every wavefront is through with the frame's tables)
         if (wave == 0) {
             if (state == 2) {   // massive ties: the literal list replay decodes this frame
@@ -2175,7 +2180,6 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
                 const PbCarry &c2 = *reinterpret_cast<const PbCarry *>(rec + kPbRecScalars);
                 const u64 hm = c2.hm, hp = c2.hp;
                 const long long f = c2.f;
-                const unsigned po = rec[kPbRecPerm + lane];
                 const int o1 = (int)(po & 255u), o2 = (int)(po >> 8);
                 if (lane < 2) L.one.cw[lane] = 0;
                 wave_fence();
