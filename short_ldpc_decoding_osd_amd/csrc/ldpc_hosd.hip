@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void hosd_front_kernel(const float *__restrict
 }
 
 constexpr int kHosdMaxBlocks = 1024;   // keys kept in LDS (8 KiB); the reference's paths have 30 blocks
-constexpr int kHosdChunk = 256;        // TEPs per work item (a block larger than this is split)
+constexpr int kHosdLdsTeps = 2560;     // a TEP table up to this size is kept in LDS and scanned in per-thread runs (the reference's order-2 paths: 2081)
+constexpr int kHosdChunk = 256;        // larger tables: TEPs per work item (a block larger than this is split)
 
 struct __attribute__((aligned(16))) HSearchLds {
     float lut[16][256];   // lut[b][v]: partial metric of discrepancy byte b (updated positions 8b..8b+7)
@@ -83,6 +84,12 @@ struct __attribute__((aligned(16))) HSearchLds {
     u64 hgL, hgM, mrb0, DL0, best, cw[2];
     int ticket;
     unsigned char o[128]; // original bit index of updated position p
+};
+// the extra tables of the per-thread-run form (a TEP table that fits: 14 KiB more, 4 instead of 6 workgroups per CU)
+template <bool RUNS>
+struct __attribute__((aligned(16))) HRunsLds {
+    int boff[RUNS ? kHosdMaxBlocks + 1 : 1];     // block_off, once per workgroup
+    uchar4 tl[RUNS ? kHosdLdsTeps : 1];          // the TEP table, once per workgroup
 };
 
 __device__ __forceinline__ float hosd_cost(const HSearchLds &L, u64 DL, u64 DM)
@@ -104,10 +111,13 @@ __device__ __forceinline__ void hosd_apply(const HSearchLds &L, uchar4 s, u64 &D
     if (s.w > 2) { DL ^= L.Mcol[s.z]; DM ^= 1ull << s.z; }
 }
 
-// One frame per 256-thread workgroup: the four wavefronts share the frame's LUTs and pull work items
-// (a TEP block, or a 256-TEP slice of a large one) from an LDS ticket counter; per-block minima are
-// combined with 64-bit LDS atomics on (metric bits, TEP index) keys -- metrics are sums of magnitudes,
-// so their bit patterns order like the floats and the smallest key is the FIRST minimum.
+// One frame per 256-thread workgroup: the four wavefronts share the frame's LUTs.  Every thread scans ITS OWN run of
+// consecutive TEPs (ceil(N / 256), made odd: LDS banks) and keeps a running first minimum that it flushes -- a 64-bit LDS
+// atomicMin on the block's (metric bits, TEP index) key -- when its run crosses into the next block and at its end: ~1.2
+// atomics per thread and frame, no per-block wave reductions (round 1-2: work items pulled from an LDS ticket, a wave
+// arg-min and an atomic per item -- 40 % of the kernel's instructions for the reference's 28 blocks of ~75 TEPs).
+// Metrics are sums of magnitudes, so their bit patterns order like the floats and the smallest key is the FIRST minimum.
+template <bool RUNS>
 __global__ __launch_bounds__(256) void hosd_search_kernel(const float *__restrict__ xo, const float *__restrict__ xm,
                                                           long long F, const unsigned char *__restrict__ lri,
                                                           const unsigned char *__restrict__ uidx,
@@ -120,6 +130,23 @@ __global__ __launch_bounds__(256) void hosd_search_kernel(const float *__restric
 {
     __shared__ HSearchLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- once per workgroup, for a TEP table that fits the LDS: the block offsets and the table, this thread's run and its first block
+    // (larger tables -- order 3: 43 745 TEPs -- keep the work items of rounds 1-2: coalesced 256-TEP slices pulled from a ticket)
+    // (both instantiations are launched; the one the table's size does not ask for leaves here: the size is device data)
+    __shared__ HRunsLds<RUNS> LR[1];
+    int run0 = 0, run1 = 0, b0 = 0;
+    const int ntep = nblk > 0 ? block_off[nblk] : 0;
+    if ((ntep <= kHosdLdsTeps) != RUNS) return;
+    if constexpr (RUNS) {
+        for (int b = tid; b <= nblk; b += 256) LR[0].boff[b] = block_off[b];
+        for (int t = tid; t < ntep; t += 256) LR[0].tl[t] = teps[t];
+        __syncthreads();
+        const int per = ((ntep + 255) / 256) | 1;      // (odd: a lane's run starts on its own LDS bank)
+        run0 = tid * per < ntep ? tid * per : ntep; run1 = run0 + per < ntep ? run0 + per : ntep;
+        int lo = 0, hi = nblk;       // the block that holds TEP run0: the last b with boff[b] <= run0 (blocks may be empty)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (LR[0].boff[mid] <= run0) lo = mid; else hi = mid; }
+        b0 = lo;
+    }
 
     for (long long f = blockIdx.x; f < F; f += gridDim.x) {
         // ---- phase 0: values in updated order (:172-176), hard decisions, M columns, key reset --------
@@ -157,33 +184,52 @@ __global__ __launch_bounds__(256) void hosd_search_kernel(const float *__restric
             const float t = hosd_cost(L, labL ^ L.hgL, labM ^ L.hgM);     // (:181-183)
             if (lane == 0) truth[f] = t;
         }
-        // ---- phase 2: the scan; items are numbered block by block, slice by slice -----------------------
-        {
-            int item = 0, b = 0, s = nblk > 0 ? block_off[0] : 0, t1 = nblk > 0 ? block_off[1] : 0;
-            for (;;) {
-                int want = 0;
-                if (lane == 0) want = atomicAdd(&L.ticket, 1);
-                want = __builtin_amdgcn_readfirstlane(want);
-                // advance (b, s) to item `want`; empty blocks own no item
-                while (b < nblk) {
-                    if (s >= t1) { ++b; if (b < nblk) { s = block_off[b]; t1 = block_off[b + 1]; } continue; }
-                    if (item == want) break;
+        if constexpr (RUNS) {
+            // ---- phase 2: the scan: this thread's run, a flush per block boundary -----------------------------
+            int b = b0;
+            float best = INFINITY;
+            int bestt = 0;
+            for (int t = run0; t < run1; ++t) {
+                while (t >= LR[0].boff[b + 1]) {      // the run leaves block b (the next ones may be empty)
+                    if (best < INFINITY) atomicMin(&L.keys[b], ((u64)(unsigned)__float_as_int(best) << 32) | (unsigned)bestt);
+                    best = INFINITY;
+                    ++b;
+                }
+                u64 DL = DL0, DM = DM0;
+                hosd_apply(L, LR[0].tl[t], DL, DM);
+                const float c = hosd_cost(L, DL, DM);
+                if (c < best) { best = c; bestt = t; }                     // ascending t: first minimum
+            }
+            if (best < INFINITY) atomicMin(&L.keys[b], ((u64)(unsigned)__float_as_int(best) << 32) | (unsigned)bestt);
+        } else {
+            // ---- phase 2: the scan; items are numbered block by block, slice by slice -----------------------
+            {
+                int item = 0, b = 0, s = nblk > 0 ? block_off[0] : 0, t1 = nblk > 0 ? block_off[1] : 0;
+                for (;;) {
+                    int want = 0;
+                    if (lane == 0) want = atomicAdd(&L.ticket, 1);
+                    want = __builtin_amdgcn_readfirstlane(want);
+                    // advance (b, s) to item `want`; empty blocks own no item
+                    while (b < nblk) {
+                        if (s >= t1) { ++b; if (b < nblk) { s = block_off[b]; t1 = block_off[b + 1]; } continue; }
+                        if (item == want) break;
+                        ++item; s += kHosdChunk;
+                    }
+                    if (b >= nblk) break;
+                    const int e = s + kHosdChunk < t1 ? s + kHosdChunk : t1;
+                    float best = INFINITY;
+                    int bestt = 0x7FFFFFFF;
+                    for (int t = s + lane; t < e; t += 64) {
+                        u64 DL = DL0, DM = DM0;
+                        hosd_apply(L, teps[t], DL, DM);
+                        const float c = hosd_cost(L, DL, DM);
+                        if (c < best) { best = c; bestt = t; }                 // ascending t per lane: first minimum
+                    }
+                    const int wl = wave_argmin_lane(best, bestt);
+                    if (lane == wl)
+                        atomicMin(&L.keys[b], ((u64)(unsigned)__float_as_int(best) << 32) | (unsigned)bestt);
                     ++item; s += kHosdChunk;
                 }
-                if (b >= nblk) break;
-                const int e = s + kHosdChunk < t1 ? s + kHosdChunk : t1;
-                float best = INFINITY;
-                int bestt = 0x7FFFFFFF;
-                for (int t = s + lane; t < e; t += 64) {
-                    u64 DL = DL0, DM = DM0;
-                    hosd_apply(L, teps[t], DL, DM);
-                    const float c = hosd_cost(L, DL, DM);
-                    if (c < best) { best = c; bestt = t; }                 // ascending t per lane: first minimum
-                }
-                const int wl = wave_argmin_lane(best, bestt);
-                if (lane == wl)
-                    atomicMin(&L.keys[b], ((u64)(unsigned)__float_as_int(best) << 32) | (unsigned)bestt);
-                ++item; s += kHosdChunk;
             }
         }
         __syncthreads();
@@ -283,7 +329,13 @@ int ldpc_hosd_search(ldpc_ctx *ctx, const float *d_order_llr, const float *d_met
                     ctx->code.m, ctx->code.k);
     if (nblk > kHosdMaxBlocks) return fail(LDPC_E_UNSUPPORTED, "ldpc_hosd_search: %d TEP blocks, at most %d", nblk, kHosdMaxBlocks);
     if (F == 0) return LDPC_OK;
-    hipLaunchKernelGGL(hosd_search_kernel, dim3(grid_for(F, 1)), dim3(256), 0, (hipStream_t)stream, d_order_llr, d_metric_llr,
+    // (the TEP table's size is device data: both forms are launched and one of them returns at once)
+    hipLaunchKernelGGL(hosd_search_kernel<true>, dim3(grid_for(F, 1)), dim3(256), 0, (hipStream_t)stream, d_order_llr, d_metric_llr,
+                       (long long)F, d_lri, d_uidx, reinterpret_cast<const u64 *>(d_M),
+                       reinterpret_cast<const uchar4 *>(d_teps), d_block_off, (int)nblk,
+                       reinterpret_cast<const u64 *>(d_label_bits), d_block_min, d_block_arg, d_truth,
+                       reinterpret_cast<u64 *>(d_cw), d_metric, d_best);
+    hipLaunchKernelGGL(hosd_search_kernel<false>, dim3(grid_for(F, 1)), dim3(256), 0, (hipStream_t)stream, d_order_llr, d_metric_llr,
                        (long long)F, d_lri, d_uidx, reinterpret_cast<const u64 *>(d_M),
                        reinterpret_cast<const uchar4 *>(d_teps), d_block_off, (int)nblk,
                        reinterpret_cast<const u64 *>(d_label_bits), d_block_min, d_block_arg, d_truth,
