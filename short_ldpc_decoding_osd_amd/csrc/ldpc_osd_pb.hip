@@ -87,6 +87,7 @@ struct PbParams {
     int budget_s, budget_m;      // ... when its sub-list is short (< 128 frames) / of medium length (< 448)
     int budget_l, budget_xl;     // ... long (1400 .. 3000) / very long
     int coop_lifo;
+    int late_min, late_maxlen, late_pct, late_div;   // frames of list A beyond late_pct % of a sub-list (if the list holds more than late_min frames) leave after budget / late_div
     int handoff_maxlen;          // ... if its sub-list of list A holds fewer frames than this (many searches: throughput counts, none leaves)
     float c4;
     long long cmin_off;          // offset of the spilled chunk minima inside a wave's global area
@@ -1305,7 +1306,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
     const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);      // TEPs of weight 1..order
     // TEPs after which a search may leave for the workgroup kernel: the fewer frames search, the sooner (a lone wavefront
     // takes ~30 us per chunk of ~400 TEPs, the workgroup ~12 us per chunk of ~2700; the schedule and its measurements: launch_pb)
-    const int budget = len < 128 ? P.budget_s : (len < 448 ? P.budget_m : (len < 1400 ? P.budget : (len < 3000 ? P.budget_l : P.budget_xl)));
+    const int budget0 = len < 128 ? P.budget_s : (len < 448 ? P.budget_m : (len < 1400 ? P.budget : (len < 3000 ? P.budget_l : P.budget_xl)));
     bool have_cdfh = false;
     for (int k = blockIdx.x >> 4; k < len; k += gridDim.x >> 4) {
         if (!have_cdfh) {
@@ -1313,6 +1314,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
             if (lane == 0) L.cdfH[64] = (float)cdf_half[64];
             have_cdfh = true;
         }
+        // (a frame that starts late -- its workgroup waited for a slot -- would end the launch if it ran long here: it leaves sooner)
+        const int budget = (len * kPbSub > P.late_min && len < P.late_maxlen && k * 100 >= len * P.late_pct) ? budget0 / P.late_div : budget0;
         const long long f = listA[sub * sub_cap + k];
         const long long src = index ? index[f] : f;
         if constexpr (PROF) { long long t = src; asm volatile("s_waitcnt vmcnt(0)" : "+v"(t)); PBW_STAMP(kPwLoad1); }
@@ -2494,6 +2497,10 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     if (const char *e = getenv("LDPC_PB_BUDGET_L")) pp.budget_l = atoi(e);
     if (const char *e = getenv("LDPC_PB_BUDGET_XL")) pp.budget_xl = atoi(e);
     if (const char *e = getenv("LDPC_PB_T3")) pp.t3 = atoi(e);
+    pp.late_min = 4608; pp.late_maxlen = 4400; pp.late_pct = 1000; pp.late_div = 4;
+    if (const char *e = getenv("LDPC_PB_LATE_PCT")) pp.late_pct = atoi(e);
+    if (const char *e = getenv("LDPC_PB_LATE_DIV")) pp.late_div = atoi(e);
+    if (const char *e = getenv("LDPC_PB_LATE_MIN")) pp.late_min = atoi(e);
     pp.coop_lifo = 1;
     if (const char *e = getenv("LDPC_PB_LIFO")) pp.coop_lifo = atoi(e);
     if (const char *e = getenv("LDPC_PB_T2")) pp.t2 = atoi(e);
