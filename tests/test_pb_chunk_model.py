@@ -124,3 +124,93 @@ def test_sum_range_enumeration(order):
             assert not seen[ids].any()
             seen[ids] = True
         assert seen.all()
+
+
+def _items():
+    """The 2017 items of csrc/ldpc_osd_pb.hip (pbw_item): item (row q, lane l) -> fixed positions and the base of its members
+    (members are the last positions m in (base, 63])."""
+    out = {}
+    for q in range(32):
+        for l in range(64):
+            if q < 31:
+                if l == 63:
+                    continue                                   # lane 63 owns no triple item
+                first = l < 62 - q
+                i, j = (q, q + 1 + l) if first else (61 - q, l)
+                out[(q, l)] = ((i, j), j)
+            else:
+                out[(q, l)] = ((l,), l) if l <= 62 else ((), -1)   # the pairs of i = l; lane 63: the singles
+    return out
+
+
+def test_items_partition_the_tep_table():
+    """Every TEP of weight 1..3 over 64 positions is a member of exactly one item (the walk of the chunk kernel and the
+    bisection counts of the workgroup kernel enumerate items, not TEPs)."""
+    seen = set()
+    for (q, l), (fixed, base) in _items().items():
+        for m in range(base + 1, 64):
+            t = tuple(sorted(fixed + (m,)))
+            assert len(set(t)) == len(t) and t not in seen, (q, l, t)
+            seen.add(t)
+    assert len(seen) == 64 + 2016 + 41664
+
+
+def test_workgroup_kernel_dealing_is_a_bijection():
+    """coop_item (csrc/ldpc_osd_pb.hip): item j of lane `lane` in wavefront v is row q = 16 j + lane / 4, lane
+    l = (13 (v - 3 q) mod 16) + 16 (lane mod 4), i.e. the items with (5 l + 3 q) mod 16 = v: every (q, l) exactly once."""
+    seen = set()
+    for v in range(16):
+        for j in range(2):
+            for lane in range(64):
+                q = 16 * j + (lane >> 2)
+                l = ((13 * (v - 3 * q)) & 15) + 16 * (lane & 3)
+                assert (5 * l + 3 * q) % 16 == v
+                assert (q, l) not in seen
+                seen.add((q, l))
+    assert len(seen) == 32 * 64
+
+
+def test_workgroup_kernel_dealing_balances_a_chunk(np_code):
+    """What the dealing is for: over the depths of a search, the sixteen wavefronts generate about the same number of a
+    chunk's keys (whole rows per wavefront: the fullest holds 1.4-1.9 times the mean and the others wait for it)."""
+    y, _ = _failed(np_code, 2.5, 200, seed=3)
+    items = _items()
+    worst = []
+    for fr in y[:6]:
+        w = np.sort(np.abs(fr))[::-1][:64].astype(np.float32)          # stand-in for the MRB reliabilities, descending
+        sums, owner = [], []
+        for (q, l), (fixed, base) in items.items():
+            sb = np.float32(sum(w[p] for p in fixed)) if fixed else np.float32(0)
+            for m in range(base + 1, 64):
+                sums.append(sb + w[m]); owner.append((5 * l + 3 * q) % 16)
+        order = np.argsort(np.array(sums), kind="stable")
+        owner = np.array(owner)[order]
+        for lo in range(1024, 40000, 2700):
+            c = np.bincount(owner[lo:lo + 2700], minlength=16)
+            worst.append(c.max() / (2700 / 16))
+    assert np.mean(worst) < 1.2 and max(worst) < 1.5
+
+
+def test_bisection_count_equals_enumeration():
+    """coop_count (csrc/ldpc_osd_pb.hip): inside an item the float32 sums sb + w[m] fall as m rises (w is sorted descending,
+    float addition is monotone), so the members <= T beyond the cursor a are the positions [first, a) and seven bisection
+    steps find `first` for any base in [-1, 63] and cursor in [base + 1, 64] -- also with equal reliabilities."""
+    rng = np.random.default_rng(11)
+    for trial in range(300):
+        w = np.sort(np.abs(rng.standard_normal(64)).astype(np.float32))[::-1].copy()
+        if trial % 3 == 0:
+            w = (np.round(w * 8) / 8).astype(np.float32)              # ties
+        sb = np.float32(rng.uniform(0, 3))
+        base = int(rng.integers(-1, 64))
+        a = int(rng.integers(base + 1, 65))
+        T = np.float32(sb + rng.uniform(0, 3))
+        lo, hi = base + 1, a
+        for _ in range(7):
+            act = lo < hi
+            mid = (lo + hi) >> 1
+            f = np.float32(sb + w[mid & 63]) <= T
+            hi = mid if act and f else hi
+            lo = mid + 1 if act and not f else lo
+        want = [m for m in range(base + 1, a) if np.float32(sb + w[m]) <= T]
+        assert lo >= hi, (base, a)
+        assert want == list(range(hi, a)), (trial, base, a, hi, want[:3])
