@@ -86,7 +86,6 @@ struct PbParams {
     int t3, budget;              // chunk target of the workgroup kernel; TEPs after which a frame may be handed to it
     int budget_s, budget_m;      // ... when its sub-list is short (< 128 frames) / of medium length (< 448)
     int budget_l, budget_xl;     // ... long (1400 .. 3000) / very long
-    int coop_lifo;
     int late_min, late_maxlen, late_pct, late_div;   // frames of list A beyond late_pct % of a sub-list (if the list holds more than late_min frames) leave after budget / late_div
     int handoff_maxlen;          // ... if its sub-list of list A holds fewer frames than this (many searches: throughput counts, none leaves)
     float c4;
@@ -2092,8 +2091,7 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
         if (tk >= nlist) break;
         int next_tk = 0;      // (drawn now, parked in LDS at the frame's end: the wavefront does not wait for the atomic here)
         if (tid == 0) { next_tk = atomicAdd(&ctl[kPbCtlTicketC], 1); L.ncand[0] = 0; L.ncand[1] = 0; }
-        // (records are taken last-in first-out: the searches handed over late started late or ran long in the chunk kernel)
-        const unsigned *rec = carry + (long long)(P.coop_lifo ? nlist - 1 - tk : tk) * kPbRecWords;
+        const unsigned *rec = carry + (long long)tk * kPbRecWords;
         // the frame's tables: one load per thread (wavefront 0 may still be writing the previous frame's codeword out)
         if (tid >= 64 && tid < 64 + kPbRecPrefix) reinterpret_cast<unsigned *>(&L.one)[tid - 64] = rec[tid - 64];
         const PbCarry &c = *reinterpret_cast<const PbCarry *>(rec + kPbRecScalars);
@@ -2163,7 +2161,7 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
                     for (int j = 0; j < NI; ++j) I.a[j] = L.sv[j][lane];
                     Fr = L.su.fr; d0 = L.su.d0; lo = L.su.lo; T = L.su.T; tprev = L.su.tprev; nprev = L.su.nprev; smax = L.su.smax;
                     done = L.su.done; n = L.su.n; R.seq = L.su.seq; R.par = L.su.par; it = L.su.it; tk = L.su.tk;
-                    rec = carry + (long long)(P.coop_lifo ? nlist - 1 - tk : tk) * kPbRecWords;
+                    rec = carry + (long long)tk * kPbRecWords;
                     po = rec[kPbRecPerm + lane];
                     next_tk = L.su.next_tk;
                 }
@@ -2501,8 +2499,6 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     if (const char *e = getenv("LDPC_PB_LATE_PCT")) pp.late_pct = atoi(e);
     if (const char *e = getenv("LDPC_PB_LATE_DIV")) pp.late_div = atoi(e);
     if (const char *e = getenv("LDPC_PB_LATE_MIN")) pp.late_min = atoi(e);
-    pp.coop_lifo = 1;
-    if (const char *e = getenv("LDPC_PB_LIFO")) pp.coop_lifo = atoi(e);
     if (const char *e = getenv("LDPC_PB_T2")) pp.t2 = atoi(e);
     if (const char *e = getenv("LDPC_PB_T1")) pp.t1 = atoi(e);
    // chunk targets: the first chunk's count is only guessed (+-40 %), the others follow the growth of the counts
@@ -2569,7 +2565,7 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
         unsigned long long h[kPcSlots];
         LDPC_HIP(hipMemcpyAsync(h, d_pc, sizeof(h), hipMemcpyDeviceToHost, s));
         LDPC_HIP(hipStreamSynchronize(s));
-        static const char *names[kPcSlots] = {"setup", "walk", "scan", "solo", "out", "FRAMES", "CHUNKS", "SOLOS", "SOLOKEYS", "KEYS", "WALKS", "TRIPS", "w_list", "w_dense", "w_collect", "w_barrier", "w_pick", "s_probe", "s_keys", "s_bar1", "s_surv", "s_bar2", "s_cand", "s_min", "s_pos"};
+        static const char *names[kPcSlots] = {"setup", "walk", "scan", "solo", "out", "FRAMES", "CHUNKS", "SOLOS", "SOLOKEYS", "KEYS", "COUNTS", "-", "-", "count", "generate", "count_exchange", "bound", "s_probe", "s_keys", "-", "s_survivors", "s_exchange", "s_candidates", "s_min", "s_positions"};
         fprintf(stderr, "[LDPC_PB_PROFILE] workgroup kernel, shader-clock ticks of thread 0 summed over workgroups:");
         for (int q = 0; q < kPcSlots; ++q) fprintf(stderr, " %s=%llu", names[q], h[q]);
         fprintf(stderr, "\n");
