@@ -141,3 +141,52 @@ def test_pb_workgroup_kernel_ties(dec, quant, monkeypatch):
     idx = np.flatnonzero(fail)[:96]
     ref = _check(dec, y[idx], cw[idx], 3, 1.0, None)
     assert ref["num_teps"].max() > 8000
+
+
+@pytest.mark.parametrize("snr,B", [(2.5, 131072), (1.0, 65536)])
+def test_pb_full_size_properties(dec, snr, B):
+    """BASELINE config 5 sizes: size-independent properties of PB-OSD order 3 on the NMS failures of a full batch.
+    The chunk bounds, the hand-over to the workgroup kernel and the order of the keys inside a chunk depend on the batch
+    (list lengths) and on timing; the results must not: two runs agree bit for bit, and so does the same set of frames
+    decoded in slices of 3000 (other budgets, other hand-overs).  Every output is a codeword whose reported metric is its
+    weighted Hamming distance; the conventional order-3 scan (all 43 745 TEPs) is never worse and equal where no rule fired."""
+    from short_ldpc_decoding_osd_amd import _lib
+    g = torch.Generator(device=dec.device).manual_seed(int(snr * 10))
+    G = to_dev(dec.code.G, dec, torch.float32)
+    Hm = to_dev(dec.code.H, dec, torch.float32)
+    cw = (torch.randint(0, 2, (B, 64), device=dec.device, generator=g).to(torch.float32) @ G).remainder(2)
+    sigma = np_oracle.snr_to_sigma(snr, 64, 128)
+    y = ((1 - 2 * cw) * (1 + sigma * torch.randn((B, 128), device=dec.device, generator=g))).contiguous()
+    res = dec.nms(y, 10, ALPHA0)
+    index, count = dec.compact(res["fail"])
+    nf = int(count.cpu()[0])
+    idx = index[:nf].to(torch.int64)
+    yf = y[idx].contiguous()
+
+    def run(yy, n):
+        aux = torch.zeros((n, 4), dtype=torch.int32, device=dec.device)
+        out = dec.osd_decode(yy, 3, params=dec.osd_params(3, _lib.OSD_PB, snr_db=snr, aux=aux))
+        torch.cuda.synchronize()
+        return {k: out[k][:n].clone() for k in ("cw", "metric", "best", "ntep")} | {"aux": aux}
+
+    a, b = run(yf, nf), run(yf, nf)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k                                     # timing-independent
+    step = 3000
+    for s in range(0, nf, step * 7):                                          # (every seventh slice: a few dozen launches)
+        e = min(s + step, nf)
+        c = run(yf[s:e].contiguous(), e - s)
+        for k in a:
+            assert torch.equal(a[k][s:e], c[k]), (k, s)                       # batch-independent
+    bits = dec.unpack_bits(a["cw"].contiguous()).to(torch.float32)
+    assert not ((bits @ Hm.T).remainder(2) != 0).any()
+    disc = (bits != (yf <= 0).to(torch.float32)).to(torch.float32)
+    wsum = (disc.double() * yf.abs().double()).sum(1)
+    assert torch.allclose(wsum, a["metric"].double(), rtol=1e-5, atol=1e-5)
+    full = dec.osd_decode(yf, 3)
+    torch.cuda.synchronize()
+    assert (full["metric"][:nf] <= a["metric"]).all()
+    nostop = a["aux"][:, 3] == 0
+    assert (a["ntep"][nostop] == 43745).all() and (a["ntep"][~nostop] < 43745).all()
+    assert torch.equal(full["metric"][:nf][nostop], a["metric"][nostop])
+    assert a["ntep"].float().mean() < 43745 / 10
