@@ -841,6 +841,7 @@ __device__ __forceinline__ int pbw_scan_chunk(PbWaveLds<CAP> &L, const PbParams 
                                               PbwState &S, int &stop, int &ntep)
 {
     constexpr int PER = CAP / 64;
+    static_assert(PER % 4 == 0, "the pass reads its keys four slices at a time");
     if (S.nlive <= 1) return -1;      // (the first chunk: one entry in the frontier, its pops are counted one by one)
     const float best0 = S.best;
     // Rule 1 by probes.  With the best fixed, the rule's left-hand side bs = H[beta] + (A[beta] - H[beta]) w1 falls as the sum
