@@ -73,26 +73,27 @@ __global__ __launch_bounds__(256) void hosd_front_kernel(const float *__restrict
 }
 
 constexpr int kHosdMaxBlocks = 1024;   // keys kept in LDS (8 KiB); the reference's paths have 30 blocks
-constexpr int kHosdLdsTeps = 2560;     // a TEP table up to this size is kept in LDS and scanned in per-thread runs (the reference's order-2 paths: 2081)
+constexpr int kHosdLdsTeps = 2304;     // a TEP table up to this size (256 threads x 9) of weight <= 2 in <= kHosdRunBlocks blocks is kept in LDS,
+constexpr int kHosdRunBlocks = 128;    // two bytes per TEP, and scanned in per-thread runs (the reference's order-2 paths: 2081 TEPs, 28 blocks)
 constexpr int kHosdChunk = 256;        // larger tables: TEPs per work item (a block larger than this is split)
 
+// RUNS: the per-thread-run form (a small table: 23 KiB of LDS, 6 workgroups per CU -- the kernel answers to occupancy: 0.34 ms at
+// 4 workgroups per CU with 4-byte TEPs and 1024 block keys, 0.31 at 5); otherwise rounds 1-2's work items (25.7 KiB).
+template <bool RUNS>
 struct __attribute__((aligned(16))) HSearchLds {
     float lut[16][256];   // lut[b][v]: partial metric of discrepancy byte b (updated positions 8b..8b+7)
     u64 Mcol[64];         // column j of updated_M (bit r = M[r][j])
     float w[128];         // |metric_llr| in updated order
-    u64 keys[kHosdMaxBlocks];   // per block: (metric bits << 32) | TEP index, minimum = first minimum
+    u64 keys[RUNS ? kHosdRunBlocks : kHosdMaxBlocks];   // per block: (metric bits << 32) | TEP index, minimum = first minimum
     u64 hgL, hgM, mrb0, DL0, best, cw[2];
-    int ticket;
+    int ticket, heavy;
     unsigned char o[128]; // original bit index of updated position p
-};
-// the extra tables of the per-thread-run form (a TEP table that fits: 14 KiB more, 4 instead of 6 workgroups per CU)
-template <bool RUNS>
-struct __attribute__((aligned(16))) HRunsLds {
-    int boff[RUNS ? kHosdMaxBlocks + 1 : 1];     // block_off, once per workgroup
-    uchar4 tl[RUNS ? kHosdLdsTeps : 1];          // the TEP table, once per workgroup
+    int boff[RUNS ? kHosdRunBlocks + 1 : 1];            // block_off, once per workgroup
+    unsigned short tl[RUNS ? kHosdLdsTeps : 2];         // the TEP table, once per workgroup: x | y << 6 | weight << 12
 };
 
-__device__ __forceinline__ float hosd_cost(const HSearchLds &L, u64 DL, u64 DM)
+template <class LDS>
+__device__ __forceinline__ float hosd_cost(const LDS &L, u64 DL, u64 DM)
 {
     float acc = lut_byte<0>(L.lut, DL);
     acc = acc + lut_byte<1>(L.lut, DL); acc = acc + lut_byte<2>(L.lut, DL); acc = acc + lut_byte<3>(L.lut, DL);
@@ -104,7 +105,8 @@ __device__ __forceinline__ float hosd_cost(const HSearchLds &L, u64 DL, u64 DM)
     return acc;
 }
 
-__device__ __forceinline__ void hosd_apply(const HSearchLds &L, uchar4 s, u64 &DL, u64 &DM)
+template <class LDS>
+__device__ __forceinline__ void hosd_apply(const LDS &L, uchar4 s, u64 &DL, u64 &DM)
 {
     if (s.w > 0) { DL ^= L.Mcol[s.x]; DM ^= 1ull << s.x; }
     if (s.w > 1) { DL ^= L.Mcol[s.y]; DM ^= 1ull << s.y; }
@@ -128,23 +130,32 @@ __global__ __launch_bounds__(256) void hosd_search_kernel(const float *__restric
                                                           u64 *__restrict__ cw_out, float *__restrict__ metric_out,
                                                           int *__restrict__ best_out)
 {
-    __shared__ HSearchLds L;
+    __shared__ HSearchLds<RUNS> L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // ---- once per workgroup, for a TEP table that fits the LDS: the block offsets and the table, this thread's run and its first block
-    // (larger tables -- order 3: 43 745 TEPs -- keep the work items of rounds 1-2: coalesced 256-TEP slices pulled from a ticket)
-    // (both instantiations are launched; the one the table's size does not ask for leaves here: the size is device data)
-    __shared__ HRunsLds<RUNS> LR[1];
+    // Both instantiations are launched and decide alike from device data which of them works (the other returns here): the
+    // per-thread-run form takes a table of <= kHosdLdsTeps TEPs of weight <= 2 in <= kHosdRunBlocks blocks.
     int run0 = 0, run1 = 0, b0 = 0;
     const int ntep = nblk > 0 ? block_off[nblk] : 0;
-    if ((ntep <= kHosdLdsTeps) != RUNS) return;
+    bool runs = ntep <= kHosdLdsTeps && nblk <= kHosdRunBlocks;
+    if (runs) {         // (uniform) any TEP of weight 3?
+        if (tid == 0) L.heavy = 0;
+        __syncthreads();
+        bool h = false;
+        for (int t = tid; t < ntep; t += 256) h |= teps[t].w > 2;
+        if (h) L.heavy = 1;
+        __syncthreads();
+        runs = L.heavy == 0;
+    }
+    if (runs != RUNS) return;
     if constexpr (RUNS) {
-        for (int b = tid; b <= nblk; b += 256) LR[0].boff[b] = block_off[b];
-        for (int t = tid; t < ntep; t += 256) LR[0].tl[t] = teps[t];
+        // once per workgroup: the block offsets and the table in LDS, this thread's run and its first block
+        for (int b = tid; b <= nblk; b += 256) L.boff[b] = block_off[b];
+        for (int t = tid; t < ntep; t += 256) { const uchar4 s = teps[t]; L.tl[t] = (unsigned short)(s.x | (s.y << 6) | (s.w << 12)); }
         __syncthreads();
         const int per = ((ntep + 255) / 256) | 1;      // (odd: a lane's run starts on its own LDS bank)
         run0 = tid * per < ntep ? tid * per : ntep; run1 = run0 + per < ntep ? run0 + per : ntep;
         int lo = 0, hi = nblk;       // the block that holds TEP run0: the last b with boff[b] <= run0 (blocks may be empty)
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (LR[0].boff[mid] <= run0) lo = mid; else hi = mid; }
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.boff[mid] <= run0) lo = mid; else hi = mid; }
         b0 = lo;
     }
 
@@ -190,13 +201,14 @@ __global__ __launch_bounds__(256) void hosd_search_kernel(const float *__restric
             float best = INFINITY;
             int bestt = 0;
             for (int t = run0; t < run1; ++t) {
-                while (t >= LR[0].boff[b + 1]) {      // the run leaves block b (the next ones may be empty)
+                while (t >= L.boff[b + 1]) {      // the run leaves block b (the next ones may be empty)
                     if (best < INFINITY) atomicMin(&L.keys[b], ((u64)(unsigned)__float_as_int(best) << 32) | (unsigned)bestt);
                     best = INFINITY;
                     ++b;
                 }
                 u64 DL = DL0, DM = DM0;
-                hosd_apply(L, LR[0].tl[t], DL, DM);
+                const unsigned tv = L.tl[t];
+                hosd_apply(L, make_uchar4((unsigned char)(tv & 63u), (unsigned char)((tv >> 6) & 63u), 0, (unsigned char)(tv >> 12)), DL, DM);
                 const float c = hosd_cost(L, DL, DM);
                 if (c < best) { best = c; bestt = t; }                     // ascending t: first minimum
             }
