@@ -306,7 +306,8 @@ struct PbPrep {
     int nhead, hsuc2, hbestidx;
     u64 hbestD, hbestE;
 };
-__device__ __forceinline__ void pb_write(SearchLds &L, const SearchFrame &S, const PbOut &O, long long f, int lane, u64 bestE,
+template <class LDS>
+__device__ __forceinline__ void pb_write(LDS &L, const SearchFrame &S, const PbOut &O, long long f, int lane, u64 bestE,
                                          u64 bestD, float best, int bestidx, int ntep, int cmp, int suc1, int suc2, int stop)
 {
     search_finish(L, S, bestE, bestD, f, lane, O.cw);
@@ -328,13 +329,14 @@ __device__ __forceinline__ int wave_incl_add(int v, int) { return wave_incl_add_
 //   mode 0: normal; 1: every frame straight to list A (block kernel); 2: every frame to list B (list replay)
 // ---------------------------------------------------------------------------------------
 struct PbSinglesLds {
-    SearchLds s;
+    SearchLdsLean s;     // no byte LUTs: the kernel evaluates two candidates per frame and lane, and it answers to occupancy
     double cdfA[65], cdfH[65];
     float q[128];
     float2 tq[64];
 };
 
-// (one wavefront per workgroup: 11.2 KiB of LDS each, 14 resident per CU -- four per workgroup left 12)
+// (one wavefront per workgroup, 3.4 KiB of LDS each: the register count decides how many are resident.  With the searches' 8 KiB
+//  of LUTs it was 11.2 KiB and 14 per CU; padded to 10 per CU the kernel took 130 instead of 98 us per 33 k frames.)
 template <bool PROF>
 __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                          const int *__restrict__ count, long long F,
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
 #define PBS_STAMP(k) do { if constexpr (PROF) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); pt[k] += now__ - plast; plast = now__; } } while (0)
     __shared__ PbSinglesLds W;
     const int lane = threadIdx.x;
-    SearchLds &L = W.s;
+    SearchLdsLean &L = W.s;
     long long nframes = F;
     if (count) { const long long c = *count; nframes = c < F ? c : F; }
     const long long wave = blockIdx.x;
@@ -372,12 +374,12 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
             u64 Pr = parity_in[f * 64 + lane];
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(o1), "+v"(o2), "+v"(Pr));
             PBS_STAMP(5);
-            S = search_prepare_regs(L, y, src, o1, o2, Pr, lane);
+            S = search_prepare_regs<false>(L, y, src, o1, o2, Pr, lane);
         } else {
-            S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+            S = search_prepare<false>(L, y, src, perm_in, parity_in, f, lane);
         }
         PBS_STAMP(0);
-        const float best0 = tep_cost(L, 0.0f, S.d0);
+        const float best0 = tep_cost_direct(L.w, 0.0f, S.d0);
         const PbFrame Fr = pb_frame_setup(L.w, W.q, W.cdfA, P.c4, P.order, P.nmax, lane, best0);
         PBS_STAMP(1);
         pb_success_terms(W.q, W.tq, lane);
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
         const int nhead = (~vmask) ? __builtin_ctzll(~vmask) : 64;
         const bool valid = lane < nhead;
         const u64 D = S.d0 ^ L.P[p];
-        const float cost = valid ? tep_cost(L, rs, D) : __builtin_inff();
+        const float cost = valid ? tep_cost_direct(L.w, rs, D) : __builtin_inff();
         const float incl = wave_incl_min(cost, lane);
         float before = __shfl_up(incl, 1, 64);
         before = lane == 0 ? best0 : __builtin_fminf(before, best0);

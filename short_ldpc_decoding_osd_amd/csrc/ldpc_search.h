@@ -14,6 +14,29 @@ struct __attribute__((aligned(16))) SearchLds {
     u64 cw[2];           // codeword being assembled in original bit order
     unsigned char perm[128];
 };
+struct __attribute__((aligned(16))) SearchLdsLean {   // the same without the byte LUTs (1.2 KiB instead of 9.4)
+    u64 P[64];
+    float w[128];
+    u64 cw[2];
+    unsigned char perm[128];
+};
+
+// The metric of tep_cost() without the LUTs: the canonical order written out (each parity byte's set positions ascending from
+// 0.0f, the byte sums added in order) -- bit-identical, ~130 instructions instead of 8 LUT reads: for kernels that evaluate
+// one or two candidates per frame.
+__device__ __forceinline__ float tep_cost_direct(const float *w, float mrb, u64 D)
+{
+    float acc = mrb;
+#pragma unroll 1
+    for (int b = 0; b < 8; ++b) {
+        const unsigned v = (unsigned)(D >> (8 * b)) & 255u;
+        float bs = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bs = ((v >> t) & 1u) ? bs + w[64 + 8 * b + t] : bs;
+        acc = acc + bs;
+    }
+    return acc;
+}
 
 template <int B>
 __device__ __forceinline__ float lut_term(const SearchLds &L, u64 D) { return lut_byte<B>(L.lut, D); }
@@ -62,8 +85,10 @@ struct SearchFrame {
 };
 
 // (LUTS = false: the caller builds the byte LUTs itself, e.g. spread over the wavefronts of a workgroup)
-template <bool LUTS = true>
-__device__ __forceinline__ SearchFrame search_prepare_regs(SearchLds &L, const float *__restrict__ y, long long src,
+// (LDS: SearchLds, or a struct with the same P / w / cw members and no LUTs -- SearchLdsLean -- for a kernel that evaluates a
+//  handful of candidates per frame and is better served by the occupancy the 8 KiB buy)
+template <bool LUTS = true, class LDS = SearchLds>
+__device__ __forceinline__ SearchFrame search_prepare_regs(LDS &L, const float *__restrict__ y, long long src,
                                                            int o1, int o2, u64 Prow, int lane)
 {
     SearchFrame S;
@@ -86,15 +111,17 @@ __device__ __forceinline__ SearchFrame search_prepare_regs(SearchLds &L, const f
     return S;
 }
 
-__device__ __forceinline__ SearchFrame search_prepare(SearchLds &L, const float *__restrict__ y, long long src,
+template <bool LUTS = true, class LDS = SearchLds>
+__device__ __forceinline__ SearchFrame search_prepare(LDS &L, const float *__restrict__ y, long long src,
                                                       const unsigned char *__restrict__ perm_in,
                                                       const u64 *__restrict__ parity_in, long long f, int lane)
 {
-    return search_prepare_regs(L, y, src, perm_in[f * 128 + lane], perm_in[f * 128 + 64 + lane], parity_in[f * 64 + lane], lane);
+    return search_prepare_regs<LUTS>(L, y, src, perm_in[f * 128 + lane], perm_in[f * 128 + 64 + lane], parity_in[f * 64 + lane], lane);
 }
 
 // candidate (E = flipped MRB positions, D = parity discrepancy) -> codeword in ORIGINAL bit order
-__device__ __forceinline__ void search_finish(SearchLds &L, const SearchFrame &S, u64 E, u64 D, long long f, int lane,
+template <class LDS>
+__device__ __forceinline__ void search_finish(LDS &L, const SearchFrame &S, u64 E, u64 D, long long f, int lane,
                                               u64 *__restrict__ cw_out)
 {
     const u64 mrb_bits = S.hm ^ E, par_bits = D ^ S.hp;
