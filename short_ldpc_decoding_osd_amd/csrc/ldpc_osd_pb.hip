@@ -133,14 +133,25 @@ __device__ __forceinline__ PbFrame pb_frame_setup(const float *w, float *q, doub
     q[lane] = 1.0f / (1.0f + det_expf(-(c4 * w[lane])));
     q[lane + 64] = 1.0f / (1.0f + det_expf(-(c4 * w[lane + 64])));
     wave_fence();
-    // sequential (ascending position) means / product, as the oracle defines them
-    float a1 = 0.0f, aw = 0.0f, at = 0.0f, spl = 1.0f;
-#pragma unroll 4
-    for (int p = 0; p < 64; ++p) {
-        a1 = a1 + q[64 + p];
-        aw = aw + w[64 + p];
-        at = at + q[p];
-        spl = spl * (1.0f - q[p]);
+    // sequential (ascending position) means / product, as the oracle defines them: four dependent chains of 64 steps.  Lanes 0..3
+    // run one chain each with ONE fused multiply-add per step -- acc * 1 + x is the sum, acc * x + 0 the product, both rounded
+    // once like the plain operations (-ffp-contract=off does not touch an explicit fma) -- instead of every lane running all four.
+    float a1, aw, at, spl;
+    {
+        const int ch = lane & 3;
+        const float *src = ch == 0 ? q + 64 : (ch == 1 ? w + 64 : q);
+        const bool prod = ch == 3;
+        float acc = prod ? 1.0f : 0.0f;
+#pragma unroll 8
+        for (int p = 0; p < 64; ++p) {
+            const float x = src[p];
+            const float b = prod ? 1.0f - x : 1.0f, c = prod ? 0.0f : x;
+            acc = __builtin_fmaf(acc, b, c);
+        }
+        a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
+        aw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 1));
+        at = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 2));
+        spl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 3));
     }
     const float p1 = a1 / 64.0f, lrb_mean = aw / 64.0f, pt = at / 64.0f;
     // The rules read cdfA[beta] with beta = clamp(floor((best - sum) / lrb_mean)), best <= best0 (the order-0 metric) and
