@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
             S = search_prepare<false>(L, y, src, perm_in, parity_in, f, lane);
         }
         PBS_STAMP(0);
-        const float best0 = tep_cost_direct(L.w, 0.0f, S.d0);
+        const float best0 = tep_cost_direct_uniform(L.w, 0.0f, S.d0, lane);
         const PbFrame Fr = pb_frame_setup(L.w, W.q, W.cdfA, P.c4, P.order, P.nmax, lane, best0);
         PBS_STAMP(1);
         pb_success_terms(W.q, W.tq, lane);

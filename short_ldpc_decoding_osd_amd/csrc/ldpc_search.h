@@ -77,6 +77,21 @@ __device__ __forceinline__ bool tep_cost_bounded(const SearchLds &L, float mrb, 
     return true;
 }
 
+// tep_cost_direct for a candidate that is the SAME in every lane (the order-0 candidate): lane b sums byte b, the byte sums are
+// added in order from lanes 0..7 -- the same operations in the same order, a quarter of the instructions.
+__device__ __forceinline__ float tep_cost_direct_uniform(const float *w, float mrb, u64 D, int lane)
+{
+    const int b = lane & 7;
+    const unsigned v = (unsigned)(D >> (8 * b)) & 255u;
+    float bs = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bs = ((v >> t) & 1u) ? bs + w[64 + 8 * b + t] : bs;
+    float acc = mrb;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bs), k));
+    return acc;
+}
+
 // per-frame set-up shared by every search: primed-order values into LDS, hard decisions, byte
 // LUTs, and the parity discrepancy d0 of the order-0 candidate
 struct SearchFrame {
