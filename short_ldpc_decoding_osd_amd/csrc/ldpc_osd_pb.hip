@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
         const u64 d0 = wave_xor64(((hm >> lane) & 1) ? Prow : 0ull) ^ hp;
         wave_fence();
         PbwState S;
-        S.best = pbw_cost_exact<CAP>(L, 0.0f, d0);
+        S.best = prep ? prep[f].hbest : tep_cost_direct_uniform(L.w, 0.0f, d0, lane);     // (the order-0 metric, or what the head made of it)
         S.j = 0; S.nlive = 1; S.cmp = 0; S.suc1 = 0; S.suc2 = 0; S.bestidx = 0; S.bestD = d0; S.bestE = 0;
         if (!prep) {  // cross-check route (every frame from its first TEP): the frame quantities are computed here
             float *q = reinterpret_cast<float *>(L.keys);
