@@ -1293,6 +1293,7 @@ struct PbCarry {
     PbFrame fr;
     u64 d0, hm, hp;
     long long f;
+    float tprev, nprev;      // the last chunk's lower bound and the TEPs before it (the growth exponent for the next bound)
 };
 constexpr int kPbRecPrefix = 520, kPbRecCur = 520, kPbRecPerm = 1032, kPbRecScalars = 1096, kPbRecWords = 1152;
 static_assert(kPbRecScalars * 4 % 8 == 0 && kPbRecScalars * 4 + sizeof(PbCarry) <= kPbRecWords * 4, "record layout");
@@ -1441,7 +1442,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
                         PbCarry c;
                         c.lo = lo; c.best = S.best; c.j = S.j; c.nlive = S.nlive; c.cmp = S.cmp; c.suc1 = S.suc1; c.suc2 = S.suc2;
                         c.bestidx = S.bestidx; c.bestD = S.bestD; c.bestE = S.bestE;
-                        c.fr = Fr; c.d0 = d0; c.hm = hm; c.hp = hp; c.f = f;
+                        c.fr = Fr; c.d0 = d0; c.hm = hm; c.hp = hp; c.f = f; c.tprev = tprev; c.nprev = nprev;
                         *reinterpret_cast<PbCarry *>(rec + kPbRecScalars) = c;
                     }
                     state = 3;
@@ -2131,7 +2132,7 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
         for (int j = 0; j < NI; ++j) I.a[j] = a0[j];
         float smax = P.order > 2 ? (L.one.w[0] + L.one.w[1]) + L.one.w[2] : (P.order > 1 ? L.one.w[0] + L.one.w[1] : L.one.w[0]);
         int stop = 0, ntep = P.nmax, state = 0;
-        float tprev = 0.0f, nprev = 0.0f;
+        float tprev = c.tprev, nprev = c.nprev;
         PBC_STAMP(kPcSetup);
         while (state == 0 && done < nall) {
             int aprev[NI];
