@@ -1998,7 +1998,8 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
         }
     }
     const int pos = coop_sum<NW>(R, wave_add_i32(cb) + (wave_add_i32(cs) << 13) + (__ballot(tie) ? 1 << 26 : 0));
-    __syncthreads();                                  // (the candidate / record words are free again)
+    // (no barrier here: the candidate / record words are next written behind the NEXT chunk's count exchange, which every
+    //  wavefront reaches only after it has left this function)
     PBC_STAMP(kPcSPos);
     if (pos >> 26) return -1;
     const int rank_best = pos & 0x1FFF, rank_stop = reason == 2 ? rank_best : (pos >> 13) & 0x1FFF;
