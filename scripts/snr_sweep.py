@@ -7,9 +7,12 @@ across the GPUs of a node and ONE RCCL all-reduce of the counters per SNR point.
 
 Prints one JSON line per SNR point (rank 0): FER_NMS, FER_OSD|fail, their product (what the reference's
 recipe multiplies by hand, `Training and Testing recipe.txt:18`), end-to-end FER, mean TEPs, frames/s.
-The reference sweeps 2.0-3.0 dB with order 3 and stops each point at 100 OSD failures
-(PB_OSD/globalmap.py:42-43): `--stop-errors 100` does the same (one 64-byte all-reduce per macro-batch, every rank
-leaves on the same macro-batch); by default every point decodes the requested number of frames.
+The reference sweeps 2.0-3.0 dB with order 3 and stops each point at 100 OSD failures, checked after every FRAME
+(PB_OSD/globalmap.py:42-43, pb_testing.py:159-174: `fail_sum`, OSD failures only).  `--stop-errors N` is the sharded form
+of that rule and is NOT line-for-line comparable with the reference's logs: it counts END-TO-END errors (OSD failures +
+NMS errors the syndrome did not flag) and checks the threshold after every MACRO-BATCH (one 64-byte all-reduce each, every
+rank leaves on the same macro-batch), so a point overshoots by up to one macro-batch of `--batch` x world frames -- use a
+small `--batch` with it; the JSON line says so (`stop_rule`).  By default every point decodes the requested number of frames.
 `--cpu-check` decodes a bounded sample of every point with the CPU port (oracle/ldpc_oracle.c, the checker) on rank 0 and
 prints `fer_vs_cpu` beside the GPU figures: +-5 % judged when both sides hold >= 1600 frame errors, else "not judged".
 """
@@ -162,14 +165,15 @@ def main():
                 main_stream.wait_event(done_ev)      # (the counters are summed on the main stream; the NEXT batch is already enqueued on the other)
             return c
 
-        total, ran = sweep_point(decode_batch, mine, args.batch, max_batches, args.stop_errors, with_osd)   # the point's exchange step(s)
+        total, ran = sweep_point(decode_batch, mine, args.batch, max_batches, args.stop_errors, with_osd, device=dec.device)   # the point's exchange step(s)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if rank == 0:
             c = total.cpu().numpy()
             out = combine_fer(c)
             out.update(snr_db=snr, osd=args.osd, order=args.order, alpha=alpha, n_gpus=world, macro_batches=ran,
-                       stop_errors=args.stop_errors, frames_per_s_incl_generation=int(c[0]) / dt)
+                       stop_errors=args.stop_errors, frames_per_s_incl_generation=int(c[0]) / dt,
+                       stop_rule=("end-to-end errors >= %d, checked per macro-batch of %d x %d frames" % (args.stop_errors, args.batch, world)) if args.stop_errors else "none: every frame decoded")
             if args.cpu_check:
                 out["fer_vs_cpu"] = cpu_check(dec.code, alpha, args, snr, end_to_end_errors(c, with_osd), int(c[0]))
             print(json.dumps(out), flush=True)

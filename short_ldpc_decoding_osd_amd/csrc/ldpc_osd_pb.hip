@@ -306,17 +306,25 @@ struct PbOut {
     u64 *cw; float *metric; int *best, *ntep, *aux;
 };
 
-// per-frame quantities of pb_frame_setup, written by the stage that computed them first (pb_singles_kernel) for the
-// frames it hands on, so that the workgroup kernels load ~1 KiB instead of repeating two 64-step sequential loops
-struct PbPrep {
-    double cdfA[65];
-    float q[128];
+// What pb_singles_kernel hands to the chunk kernel: ONE contiguous record per frame (1536 B) with everything the search
+// needs, so that the receiving wavefront starts after a single wide load instead of the chain frame number -> source
+// index -> permutation -> y (round 3; the record replaces the separate 1096-byte PbPrep table of rounds 2-3):
+//   words [0, 128)     w[128]     |y'|                                       } the head of PbWaveLds (behind its four pad
+//   words [128, 256)   P[64]      rows of P'                                 } words): the chunk kernel copies these 324 words
+//   words [256, 324)   cdfA[68]   P[Bin(64, p1) <= b] rounded to float32     } into LDS as they are
+//   words [324, 356)   perm[128]  original bit index of primed position p, one byte each
+//   words [356, ...)   PbHead     the frame's scalars and the search state after the weight-1 head
+// Derived on arrival (a few dozen instructions): the cost-bound table (sorted parity weights) and the success-rule factors.
+struct PbHead {
     PbFrame fr;
-    // the search state after the weight-1 head of the pop sequence (no rule fired on it): the chunk kernel goes on from here
+    u64 d0, hm, hp;            // order-0 parity discrepancy, hard decisions of the MRB / parity part
+    u64 hbestD, hbestE;        // the search state after the weight-1 head of the pop sequence (no rule fired on it)
     float hbest;
     int nhead, hsuc2, hbestidx;
-    u64 hbestD, hbestE;
 };
+constexpr int kPbR1Perm = 324, kPbR1Head = 356, kPbR1Words = 384;
+static_assert(kPbR1Head * 4 % 8 == 0 && kPbR1Head * 4 + sizeof(PbHead) <= kPbR1Words * 4, "record layout");
+
 template <class LDS>
 __device__ __forceinline__ void pb_write(LDS &L, const SearchFrame &S, const PbOut &O, long long f, int lane, u64 bestE,
                                          u64 bestD, float best, int bestidx, int ntep, int cmp, int suc1, int suc2, int stop)
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
                                                          const u64 *__restrict__ parity_in, PbParams P, int mode,
                                                          const double *__restrict__ cdf_half,
                                                          int *__restrict__ ctl, int *__restrict__ listA, int *__restrict__ listB, int sub_cap,
-                                                         PbPrep *__restrict__ prep, PbOut O, unsigned long long *__restrict__ prof_out)
+                                                         unsigned *__restrict__ recs, PbOut O, unsigned long long *__restrict__ prof_out)
 {
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
@@ -366,12 +374,9 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
     long long nframes = F;
     if (count) { const long long c = *count; nframes = c < F ? c : F; }
     const long long wave = blockIdx.x;
-    if (mode != 0) {   // hand every frame on, in frame order
-        for (long long f = wave * 64 + lane; f < nframes; f += (long long)gridDim.x * 64) {
-            if (mode == 1) listA[(f & (kPbSub - 1)) * sub_cap + (f >> 4)] = (int)f; else listB[f] = (int)f;
-        }
-        if (wave == 0 && mode == 1 && lane < kPbSub) ctl[kPbCtlLenA + kPbCtlLine * lane] = (int)((nframes - lane + kPbSub - 1) >> 4);
-        if (wave == 0 && mode == 2 && lane == 0) ctl[kPbCtlLenB] = (int)nframes;
+    if (mode == 2) {   // every frame to the list replay, in frame order
+        for (long long f = wave * 64 + lane; f < nframes; f += (long long)gridDim.x * 64) listB[f] = (int)f;
+        if (wave == 0 && lane == 0) ctl[kPbCtlLenB] = (int)nframes;
         return;
     }
     W.cdfH[lane] = cdf_half[lane];
@@ -396,10 +401,11 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
         pb_success_terms(W.q, W.tq, lane);
         wave_fence();
         // lane l <-> TEP {63 - l}, visit index l; valid while its weight is below the smallest weight-2 sum
+        // (mode 1, the cross-check route "every frame through the chunk kernel from its first TEP": no head at all)
         const int p = 63 - lane;
         const float rs = L.w[p];
         const float s2min = L.w[62] + L.w[63];
-        const u64 vmask = __ballot(P.order == 1 || rs < s2min);
+        const u64 vmask = mode == 1 ? 0ull : __ballot(P.order == 1 || rs < s2min);
         const int nhead = (~vmask) ? __builtin_ctzll(~vmask) : 64;
         const bool valid = lane < nhead;
         const u64 D = S.d0 ^ L.P[p];
@@ -414,10 +420,13 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
         if (newbest) stop2 = pb_success(D, w1, W.tq, Fr);
         const u64 sm = __ballot(stop1 || stop2);
         PBS_STAMP(2);
-        if (sm == 0 && P.order > 1) {   // no rule fired on the head: the block kernel takes the frame (and what was computed for it)
-            PbPrep &R = prep[f];
-            R.q[lane] = W.q[lane]; R.q[lane + 64] = W.q[lane + 64];
-            R.cdfA[lane] = W.cdfA[lane];
+        if (sm == 0 && (P.order > 1 || mode == 1)) {   // no rule fired on the head: the chunk kernel takes the frame, with ONE record
+            unsigned *const R = recs + f * kPbR1Words;
+            R[lane] = __float_as_uint(L.w[lane]); R[64 + lane] = __float_as_uint(L.w[64 + lane]);
+            reinterpret_cast<u64 *>(R + 128)[lane] = L.P[lane];
+            R[256 + lane] = __float_as_uint((float)W.cdfA[lane]);
+            if (lane < 4) R[320 + lane] = lane == 0 ? __float_as_uint((float)W.cdfA[64]) : 0u;
+            if (lane < 32) R[kPbR1Perm + lane] = reinterpret_cast<const unsigned *>(L.perm)[lane];
             {   // the head's result: nhead TEPs popped and evaluated, the last improvement among them (if any)
                 const u64 nbm = __ballot(newbest);
                 float hb = best0;
@@ -428,9 +437,15 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
                     hb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cost), lb));
                     hD = readlane64(D, lb); hE = 1ull << (63 - lb); hidx = lb + 1;
                 }
-                if (lane == 0) { R.hbest = hb; R.nhead = nhead; R.hsuc2 = __popcll(nbm); R.hbestidx = hidx; R.hbestD = hD; R.hbestE = hE; }
+                if (lane == 0) {
+                    PbHead h;
+                    h.fr = Fr; h.d0 = S.d0; h.hm = S.hm; h.hp = S.hp; h.hbestD = hD; h.hbestE = hE;
+                    h.hbest = hb; h.nhead = nhead; h.hsuc2 = __popcll(nbm); h.hbestidx = hidx;
+                    *reinterpret_cast<PbHead *>(R + kPbR1Head) = h;
+                    const int sl = (int)f & (kPbSub - 1);
+                    listA[sl * sub_cap + atomicAdd(&ctl[kPbCtlLenA + kPbCtlLine * sl], 1)] = (int)f;
+                }
             }
-            if (lane == 0) { R.cdfA[64] = W.cdfA[64]; R.fr = Fr; const int sl = (int)f & (kPbSub - 1); listA[sl * sub_cap + atomicAdd(&ctl[kPbCtlLenA + kPbCtlLine * sl], 1)] = (int)f; }
             PBS_STAMP(3);
             continue;
         }
@@ -471,28 +486,49 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
 // addition is monotone, so with the other positions fixed the sum of a TEP is non-increasing in its LAST position m.
 // The TEPs are 2017 "items" -- the singles {m}; the pairs {i, m} of one i; the triples {i, j, m} of one (i, j) --
 // inside each of which the members appear in the visit order by DESCENDING m.  Every lane owns 32 items:
-//   q = 0..30  triples, row pair q: lanes l < 62 - q own (i, j) = (q, q + 1 + l), lanes 62 - q .. 62 own (61 - q, l)
-//              (rows q and 61 - q hold 62 - q and q + 1 items: 63 together; lane 63 owns none)
+//   q = 0..30  triples, by the DISTANCE of the two fixed positions: lanes l < 62 - q own (i, j) = (l, l + 1 + q) (distance
+//              q + 1), lanes 62 - q .. 62 own (l - 62 + q, l) (distance 62 - q): 62 - q and q + 1 items, 63 together;
+//              lane 63 owns none.  In both cases one fixed position is the LANE NUMBER and the other is the lane number
+//              plus q + 1 resp. q + 2 modulo 64: the lane's own weight plus a copy of the weights that rotates through the
+//              wavefront by one lane per row (DPP wave_rol) -- the fixed sums cost no memory access and no uniform operand.
+//              (Rounds 1-3 dealt the rows by i: (q, q + 1 + l) and (61 - q, l): two LDS reads per item for the same sum.)
 //   q = 31     lanes 0..62: the pairs of i = l;  lane 63: the singles
-// and keeps per item, in registers: the sum of its fixed positions, a cursor (members [cursor, 64) are visited) and the
-// sum of its NEXT member.  The chunk (lo, T] is produced by a WALK: for each q, while any lane's next member is <= T
+// and keeps per item a cursor (members [cursor, 64) are visited; 0 = no member left).  The chunk (lo, T] is produced by a
+// WALK: every item's next member (fixed sum + the weight under the cursor) is compared with T, the items that have one are listed,
 // those lanes emit it (key = sum bits << 32 | positions; slot = running count + mbcnt of the ballot) and step their
 // cursor.  An item costs one compare when it has nothing to give, the members cost one trip each; no binary searches,
 // no count-then-write double pass, no block scan.  T can be ANY value -- exactness does not depend on it -- so it is
 // sized to the work: first guess from pb_bound_guess / the growth exponent of the last two bounds, a short chunk is
 // extended in place (the walk resumes), an overflowing walk is abandoned and retried with a smaller T.
 // ---------------------------------------------------------------------------------------
+// uniform search state of a frame (wave-uniform values)
+struct PbwState {
+    float best;
+    int j, nlive, cmp, suc1, suc2, bestidx;
+    u64 bestD, bestE;
+};
+// arguments and results of the sorted path (pbw_sorted_chunk: a real function call, made with nothing live across it)
+struct PbSortArgs {
+    PbwState S;
+    PbFrame fr;
+    u64 d0;
+    float mn, mx, c4;
+    int n, order, state, stop, ntep;
+};
+
 constexpr int kPbMaxTie = 16;
 constexpr int kPbWaveCap = 512;   // chunk capacity of the chunk kernel
 
 template <int CAP>
 struct __attribute__((aligned(16))) PbWaveLds {
-    float tail[4][17];        // tail[g][c] <= the sum of the c lightest parity weights of quarter g (pbw_cost_floor)
-    u64 P[64];                // rows of P'
-    float w[128];             // |y'|
-    float2 tq[64];            // success-rule factors (pb_success_terms)
-    float cdfA[68], cdfH[68]; // the two binomial CDF tables ROUNDED TO float32 -- the rules only ever read them through a
+    float pre[4];             // pre[3] = NaN: the "weight" under an exhausted cursor (0) -- its sum compares false with any bound
+    float w[128];             // |y'|                                         } words [4, 328): the image of the record
+    u64 P[64];                // rows of P'                                   } pb_singles_kernel wrote for the frame
+    float cdfA[68];           // P[Bin(64, p1) <= b] ROUNDED TO float32 -- the rules only ever read the table through a
                               // (float) cast (pb_not_promising), so storing the rounded value is the same arithmetic
+    float tail[4][17];        // tail[g][c] <= the sum of the c lightest parity weights of quarter g (pbw_cost_floor)
+    float2 tq[64];            // success-rule factors (pb_success_terms)
+    float cdfH[68];           // P[Bin(64, 1/2) <= b], float32 as cdfA
     // the chunk: as walked (slots 0..n-1), then -- skewed, one pad entry per eight: lane-consecutive 64-bit accesses
     // would otherwise fall on two LDS banks -- grouped by bucket and finally in visit order; 64 entries of slack take the
     // overshoot of the walk's last trip and the "never before me" pad of the rank count
@@ -502,10 +538,16 @@ struct __attribute__((aligned(16))) PbWaveLds {
         unsigned list[CAP + 64];   // the walk's work list (one entry per member emitted)
     };
     unsigned cur[8][64];      // tentative cursors of the walk: byte q & 3 of cur[q / 4][lane] = item q of that lane
-    u64 ck[16], rk[16];       // sort-free chunk pass: improvement candidates / the records among them (key, cost)
-    float cc[16], rc[16];
+    union {
+        struct {
+            u64 ck[16], rk[16];   // sort-free chunk pass: improvement candidates / the records among them (key, cost)
+            float cc[16], rc[16];
+        };
+        PbSortArgs sa;        // (the pass has given up on the chunk when the sorted path is called: its words are free)
+    };
     u64 cw[2];
 };
+static_assert(sizeof(PbSortArgs) <= 384, "the sorted path's arguments borrow the candidate words");
 
 __device__ __forceinline__ int pbw_phys(int i) { return i + (i >> 3); }
 
@@ -563,25 +605,15 @@ struct PbwItem {
     int i, j, base, sh;
     unsigned code;
 };
-__device__ __forceinline__ PbwItem pbw_item(int q, int lane)
+__device__ __forceinline__ PbwItem pbw_item_rt(int q, int l)
 {
-    // (opaque copy of the lane number: otherwise the compiler hoists the 32 items' constants out of every loop and keeps
-    //  ~100 VGPRs alive for the whole kernel; they cost three or four instructions where they are needed)
-    asm volatile("" : "+v"(lane));
     PbwItem it;
-    if (q < 31) {
-        const bool first = lane < 62 - q;
-        it.i = first ? q : 61 - q;
-        it.j = first ? q + 1 + lane : lane;
-        it.base = lane <= 62 ? it.j : 63;
-        it.code = (3u << 24) | ((unsigned)it.j << 8) | (unsigned)it.i;
-        it.sh = 16;
-    } else {
-        it.i = lane; it.j = lane;
-        it.base = lane <= 62 ? lane : -1;
-        it.code = lane <= 62 ? ((2u << 24) | (unsigned)lane) : (1u << 24);
-        it.sh = lane <= 62 ? 8 : 0;
-    }
+    const bool tri = q < 31, first = l < 62 - q;
+    it.i = tri ? (first ? l : l - 62 + q) : l;
+    it.j = tri ? (first ? l + 1 + q : l) : l;
+    it.base = tri ? (l <= 62 ? it.j : 63) : (l <= 62 ? l : -1);
+    it.code = tri ? ((3u << 24) | ((unsigned)it.j << 8) | (unsigned)it.i) : (l <= 62 ? ((2u << 24) | (unsigned)l) : (1u << 24));
+    it.sh = tri ? 16 : (l <= 62 ? 8 : 0);
     return it;
 }
 
@@ -591,11 +623,13 @@ enum { kPwSetup = 0, kPwWalk, kPwSort, kPwTie, kPwEval, kPwRules, kPwCombine, kP
        kPwSweepA, kPwSweepB, kPwDense, kPwRounds, kPwTrips, kPwScan, kPwSorted, kPwLoad1, kPwLoad2, kPwStore, kPwSlots };
 #define PBW_STAMP(k) do { if constexpr (PROF) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); pt[k] += now__ - plast; plast = now__; } } while (0)
 
-// Walk state.  Registers: for each of the lane's 32 items the sum of its NEXT member (NaN: exhausted) and the COMMITTED
-// cursors (one byte per item, four items per register; members [cursor, 64) are visited).  LDS: the TENTATIVE cursors
-// L.cur[q / 4][lane] of the chunk being sized -- in the dense phase below a lane works on whatever item the list hands it.
+// Walk state.  Registers: the COMMITTED cursors only (one byte per item, four items per register; members [cursor, 64) are
+// visited).  LDS: the TENTATIVE cursors L.cur[q / 4][lane] of the chunk being sized -- in the dense phase below a lane works on
+// whatever item the list hands it.  The sum of an item's NEXT member is NOT kept (rounds 1-3 held the 32 of them in registers:
+// with the chunk's keys that was 225 live VGPRs against the 168 of three wavefronts per SIMD, i.e. 57 registers in scratch,
+// re-read and re-written once per walk -- 0.87 GB of HBM writes per launch at 1.0 dB): it is the item's fixed sum plus the weight
+// under its cursor, two LDS reads and an add when the walk asks for it.
 struct PbWalk {
-    float nxt[32];
     unsigned ecur[8];
 };
 
@@ -617,59 +651,96 @@ __device__ __forceinline__ void pbw_cursors_load(const PbWaveLds<CAP> &L, unsign
 template <int CAP>
 __device__ __forceinline__ void pbw_walk_init(PbWaveLds<CAP> &L, PbWalk &W, int order, int lane)
 {
-    // every cursor at 64: an item's next member is its last position 63.  Written out from the item geometry (pbw_item) --
-    // going through the general helper here cost 40 spilled VGPRs of long-lived state: the 32 unrolled items' temporaries
-    // set the kernel's register peak.
-    const float *w = L.w;
-    const float wl = w[lane], w63 = w[63];
+    // every cursor at 64 (an item's next member is its last position 63); 0 for the items that do not exist: lane 63's
+    // triples, the pairs when the order is 1
 #pragma unroll
-    for (int q = 0; q < 31; ++q) {
-        const bool first = lane < 62 - q;
-        const int jj = q + 1 + lane;
-        const float wi = first ? w[q] : w[61 - q];
-        const float wj = first ? w[jj < 63 ? jj : 63] : wl;
-        float v = (lane <= 62 && order > 2) ? (wi + wj) + w63 : pbw_nan();
-        asm volatile("" : "+v"(v) : : "memory");     // (one item at a time: finished before the next one's reads are issued)
-        W.nxt[q] = v;
-    }
-    W.nxt[31] = lane <= 62 ? (order > 1 ? wl + w63 : pbw_nan()) : w63;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) W.ecur[k] = 0x40404040u;
+    for (int k = 0; k < 8; ++k) W.ecur[k] = lane <= 62 ? 0x40404040u : 0u;
+    if (lane == 63 || order < 2) W.ecur[7] = lane <= 62 ? 0x00404040u : 0x40000000u;
     pbw_cursors_store<CAP>(L, W.ecur, lane);
 }
 
-// Emit every member with sum <= T that lies beyond the tentative cursors; returns the new running count (> CAP: the chunk
-// overflowed, the walk stopped early and W.nxt still describes the cursors the walk STARTED from -- the caller puts those
-// back).  Three phases:
-//   list    one compare per item: the items whose next member is <= T are appended to a work list (ballot + mbcnt, no loop);
-//           86 % of the items have nothing to give and cost that compare;
-//   dense   the list, 64 entries per trip, every lane emits exactly ONE member of its entry's item (key = sum bits << 32 |
+// w[(lane + 1) & 63] of a register that holds w[lane] in every lane, three ways (ROT: what the context's probe of the
+// wave_rol:1 DPP control found: -1 = a lane receives its upper neighbour's value, +1 = its lower neighbour's, 0 = unusable)
+template <int ROT>
+__device__ __forceinline__ float pbw_rot1(float x)
+{
+    static_assert(ROT != 0, "no rotation: the caller reads LDS");
+    if constexpr (ROT < 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x134, 0xF, 0xF, true));   // wave_rol:1
+    else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x13C, 0xF, 0xF, true));                     // wave_ror:1
+}
+
+// Emit every member with sum <= T that lies beyond the tentative cursors (L.cur); returns the new running count (> CAP: the
+// chunk overflowed, the walk stopped early and the caller puts the committed cursors back).  Two phases:
+//   list    one pass over the lane's 32 items.  An item's next member has the sum (w[i] + w[j]) + w[cursor - 1]; one of i, j
+//           is the lane number and the other sits q + 1 or q + 2 lanes further (mod 64), so the fixed part is the lane's own
+//           weight plus a copy of the weights that moves one lane per row (pbw_rot1); the weight under the cursor is one LDS
+//           read (a cursor of 0 reads the NaN in front of the weights: no member left, no separate test); one compare.  The
+//           items whose next member is <= T are appended to a work list (ballot + mbcnt, no loop); 86 % have nothing to give;
+//   dense   the list, 64 entries per trip, every lane emits one or two members of its entry's item (key = sum bits << 32 |
 //           positions; slot = running count + mbcnt), steps that item's cursor in LDS and, if the item's next member is
-//           <= T too, appends the entry to the list's tail again -- so a trip runs at full lanes whatever the items' lengths;
-//           an item that is done leaves its new next-member sum in the list slot it first occupied;
-//   collect the owners take those sums back (same ballots, same slots; branch-free).
+//           <= T too, appends the entry to the list's tail again -- so a trip runs at full lanes whatever the items' lengths.
 // A lane works on whatever item the list hands it, hence the cursors in LDS and the item geometry from run-time (q, lane).
-// (Round 3's first form walked every item to its end where it stood -- while any lane has a member, emit --: ~80 trips per
-//  chunk at ~10 % of the lanes, 28 k of a chunk's 55 k cycles; the second listed only the items with a second member:
-//  2100 vector instructions per walk, this form ~800.)
-template <int CAP, bool PROF>
-__device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, PbWalk &W, float T, int cnt, int order, int lane,
+// (Round 3 kept the next-member sums in registers -- 32 VGPRs -- and took them back from the dense phase in a third sweep,
+//  "collect", ~9 instructions per item: 57 spilled registers re-read and re-written once per walk.)
+template <int CAP, bool PROF, int ROT>
+__device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int order, int lane,
                                         unsigned long long (&pt)[kPwSlots])
 {
     unsigned long long plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
     static_assert((CAP + 64) + (CAP + 64) / 8 >= CAP + 128, "a dense trip may write 127 keys past CAP");
-    unsigned *const list = L.list;      // entry: q | owner lane << 5 | first slot << 11
+    static_assert(offsetof(PbWaveLds<CAP>, w) >= 4 && offsetof(PbWaveLds<CAP>, w) == offsetof(PbWaveLds<CAP>, pre) + 16, "the NaN sits right in front of the weights");
+    unsigned *const list = L.list;      // entry: q | owner lane << 5
+    const float *const w = L.w;
     int tail = 0;
+    {
+        // (an opaque copy of the lane number per walk: otherwise lane-dependent addresses are hoisted out of every loop
+        //  around the walk, kept for the whole kernel and spilled)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        unsigned cur[8];
+        pbw_cursors_load<CAP>(L, cur, ln);
+        const float wl = w[ln];
+        const char *const wbytes = reinterpret_cast<const char *>(w) - 4;       // + 4 * cursor = the weight under the cursor
+        // eight items at a time: the eight sums first (their LDS reads in flight together -- a branch behind every item made
+        // the wavefront wait for each read by itself: ~32 exposed LDS latencies per walk), then the eight ballots and appends
+        const auto next_sum = [&](int q, float sb) {
+            const unsigned a4 = ((cur[q >> 2] >> (8 * (q & 3))) & 255u) << 2;
+            return sb + *reinterpret_cast<const float *>(wbytes + a4);
+        };
+        const auto append = [&](int q, float sv) {
+            const bool pend = sv <= T;
+            const u64 act = tail <= CAP ? __ballot(pend) : 0ull;      // (more than CAP pending items: an overflow already)
+            if (act) {
+                const int p = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+                if (pend) list[p] = (unsigned)q | ((unsigned)ln << 5);
+                tail += __popcll(act);
+            }
+        };
+        if (order > 2) {
+            float r1;                    // w[(lane + q + 1) & 63]
+            if constexpr (ROT != 0) r1 = pbw_rot1<ROT>(wl); else r1 = w[(ln + 1) & 63];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        if (q < 31 && order < 3) continue;
-        const bool pend = W.nxt[q] <= T;
-        const u64 act = tail <= CAP ? __ballot(pend) : 0ull;      // (more than CAP pending items: an overflow already)
-        if (act) {
-            const int p = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
-            if (pend) list[p] = (unsigned)q | ((unsigned)lane << 5) | ((unsigned)p << 11);
-            tail += __popcll(act);
+            for (int g = 0; g < 4; ++g) {
+                float sv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = 8 * g + u;
+                    if (q < 31) {
+                        float r2;
+                        if constexpr (ROT != 0) r2 = pbw_rot1<ROT>(r1); else r2 = w[(ln + q + 2) & 63];
+                        sv[u] = next_sum(q, wl + (ln < 62 - q ? r1 : r2));
+                        r1 = r2;
+                    } else {
+                        sv[u] = next_sum(31, ln <= 62 ? wl : 0.0f);
+                    }
+                }
+                asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) append(8 * g + u, sv[u]);
+            }
+        } else {
+            append(31, next_sum(31, ln <= 62 ? wl : 0.0f));
         }
     }
     PBW_STAMP(kPwSweepA);
@@ -687,7 +758,7 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, PbWalk &W, float T, i
         unsigned code;
         if (q < 31) {
             const bool first = l < 62 - q;
-            i = first ? q : 61 - q; j = first ? q + 1 + l : l; base = j; sh = 16;
+            i = first ? l : l - 62 + q; j = first ? l + 1 + q : l; base = j; sh = 16;
             code = (3u << 24) | ((unsigned)j << 8) | (unsigned)i;
         } else {
             i = l; j = l; base = l <= 62 ? l : -1; sh = l <= 62 ? 8 : 0;
@@ -695,26 +766,26 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, PbWalk &W, float T, i
         }
         unsigned char *const cb = reinterpret_cast<unsigned char *>(&L.cur[q >> 2][l]) + (q & 3);
         const int a = has ? (int)*cb : 1;
-        const float sbv = q < 31 ? L.w[i] + L.w[j] : (l <= 62 ? L.w[l] : 0.0f);
+        const float sbv = q < 31 ? w[i] + w[j] : (l <= 62 ? w[l] : 0.0f);
         // up to TWO members of the item per trip (the tail of a walk is a few long items: half the trips); the order of the
         // keys inside a chunk is irrelevant, so the second members simply follow the first ones
         const int m = a - 1;
-        const float s = sbv + L.w[m], s2 = sbv + L.w[m > 0 ? m - 1 : 0], s3 = sbv + L.w[m > 1 ? m - 2 : 0];
+        const float s = sbv + w[m], s2 = sbv + w[m > 0 ? m - 1 : 0], s3 = sbv + w[m > 1 ? m - 2 : 0];
         const bool two = has && m > base + 1 && s2 <= T;
         const int mlast = two ? m - 1 : m;
-        const float nx = mlast > base + 1 ? (two ? s3 : s2) : pbw_nan();
+        const bool left = mlast > base + 1;                 // the item has members beyond this trip's
+        const bool again = has && left && (two ? s3 : s2) <= T;
         const u64 act = __ballot(has), act2 = __ballot(two);
         const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, (unsigned)cnt));
         const int pos2 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act2, (unsigned)(cnt + __popcll(act))));
-        const bool again = has && nx <= T;
         const u64 more = __ballot(again);
         const int nt = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(more >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)more, 0u));
         wave_fence();                    // (every lane has read its entry: the slots may be written now)
         if (has) {
             L.keys[pos] = ((u64)__float_as_uint(s) << 32) | (code | ((unsigned)m << sh));
             if (two) L.keys[pos2] = ((u64)__float_as_uint(s2) << 32) | (code | ((unsigned)(m - 1) << sh));
-            *cb = (unsigned char)mlast;
-            if (again) list[nt] = ent; else list[ent >> 11] = __float_as_uint(nx);
+            *cb = (unsigned char)(left ? mlast : 0);        // (0: exhausted -- the list pass then reads the NaN)
+            if (again) list[nt] = ent;
         }
         cnt += __popcll(act) + __popcll(act2);
         head = head + 64 < tail ? head + 64 : tail;
@@ -723,21 +794,6 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, PbWalk &W, float T, i
         if (tail > CAP) { cnt = CAP + 1; break; }   // every entry ever listed is at least one member: more than CAP members, an overflow
     }
     PBW_STAMP(kPwDense);
-    if (cnt > CAP) return cnt;
-    // collect: the same ballots as above give every owner the slots of its items
-    int slot0 = 0;
-#pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        if (q < 31 && order < 3) continue;
-        const bool pend = W.nxt[q] <= T;
-        const u64 act = __ballot(pend);
-        const int p = slot0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
-        const float v = __uint_as_float(list[p]);       // (a lane without a pending item reads some slot and drops it)
-        W.nxt[q] = pend ? v : W.nxt[q];
-        slot0 += __popcll(act);
-        if ((q & 7) == 7) asm volatile("" ::: "memory");   // (eight reads in flight, not thirty-two: registers)
-    }
-    PBW_STAMP(kPwSweepB);
     return cnt;
 }
 
@@ -759,7 +815,7 @@ __device__ __forceinline__ float pb_bound_guess(float n)
 // The next chunk: walks (lo, T] for a T aimed at `target` members, 0 < n <= CAP.  Returns n and T; the chunk's keys are
 // L.keys[0..n) and the walk's cursors are committed.  -1: the range cannot be split (massively equal sums: the frame goes
 // to the list replay); 0: nothing is left to visit (NaN sums).
-template <int CAP, bool PROF>
+template <int CAP, bool PROF, int ROT>
 __device__ __forceinline__ int pbw_next_chunk(PbWaveLds<CAP> &L, PbWalk &W, int order, float lo, int done, int nall, int target, int lane,
                                               float &Tout, float &tprev, float &nprev, int &nwalks, unsigned long long (&pt)[kPwSlots],
                                               float Tcap = __builtin_inff())
@@ -781,7 +837,7 @@ __device__ __forceinline__ int pbw_next_chunk(PbWaveLds<CAP> &L, PbWalk &W, int 
     float T_ok = lo;
     unsigned a_ok[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < 48; ++it) {
-        cnt = pbw_walk<CAP, PROF>(L, W, T, cnt, order, lane, pt);
+        cnt = pbw_walk<CAP, PROF, ROT>(L, T, cnt, order, lane, pt);
         ++nwalks;
         bool over = false;
         if (cnt > CAP) {
@@ -827,13 +883,6 @@ __device__ __forceinline__ int pbw_next_chunk(PbWaveLds<CAP> &L, PbWalk &W, int 
     Tout = T_ok;
     return c_ok;
 }
-
-// uniform search state of a frame (wave-uniform values)
-struct PbwState {
-    float best;
-    int j, nlive, cmp, suc1, suc2, bestidx;
-    u64 bestD, bestE;
-};
 
 // Sort-free pass over a chunk (the n keys as the walk left them, in no particular order).  The visit order matters to the
 // rules only through (i) "best so far", which changes only at a key whose cost beats the best the chunk STARTED with -- a
@@ -1279,13 +1328,53 @@ __device__ __forceinline__ int pbw_process_chunk(PbWaveLds<CAP> &L, const PbPara
     return 0;
 }
 
+// The sorted path as a FUNCTION (not inlined): it runs for the first chunk or two of a frame that arrives without its head,
+// for 0.05 % of the chunks otherwise, and inlined it sets the register peak of every kernel that contains it (key, bucket, start
+// and rank arrays of eight entries each).  Arguments and results travel through L.sa, so that nothing is live across the call
+// but what the caller chooses to keep (the committed cursors are re-read from L.cur, which holds them after a commit).
+template <int CAP>
+__device__ __noinline__ void pbw_sorted_chunk(PbWaveLds<CAP> &L)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long pt[kPwSlots], plast = 0;
+    PbParams P;
+    P.order = L.sa.order; P.c4 = L.sa.c4;
+    const PbFrame Fr = L.sa.fr;
+    const u64 d0 = L.sa.d0;
+    const int n = L.sa.n;
+    const float mn = L.sa.mn, mx = L.sa.mx;
+    PbwState S = L.sa.S;
+    int stop = L.sa.stop, ntep = L.sa.ntep;
+    wave_fence();
+    const int state = pbw_process_chunk<CAP, false>(L, P, Fr, d0, n, mn, mx, lane, S, stop, ntep, pt, plast);
+    wave_fence();
+    if (lane == 0) { L.sa.S = S; L.sa.state = state; L.sa.stop = stop; L.sa.ntep = ntep; }
+    wave_fence();
+}
+// caller's side: park, call, take back
+template <int CAP>
+__device__ __forceinline__ int pbw_sorted_call(PbWaveLds<CAP> &L, const PbParams &P, const PbFrame &Fr, u64 d0, int n, float mn, float mx, int lane,
+                                               PbwState &S, int &stop, int &ntep)
+{
+    wave_fence();
+    if (lane == 0) {
+        L.sa.S = S; L.sa.fr = Fr; L.sa.d0 = d0; L.sa.mn = mn; L.sa.mx = mx; L.sa.c4 = P.c4; L.sa.n = n; L.sa.order = P.order;
+        L.sa.stop = stop; L.sa.ntep = ntep;
+    }
+    wave_fence();
+    pbw_sorted_chunk<CAP>(L);
+    wave_fence();
+    S = L.sa.S; stop = L.sa.stop; ntep = L.sa.ntep;
+    return L.sa.state;
+}
+
 // A long search handed from the chunk kernel to the workgroup kernel: ONE record per frame with everything the search needs,
 // so that the receiving workgroup starts after a single wide load (its 1024 threads copy the record into LDS side by side)
 // instead of the chain frame number -> source index -> permutation -> y that the chunk kernel went through:
-//   words [0, 520)      the frame's tables as they stand in PbWaveLds (tail, P, w, tq, cdfA), verbatim
-//   words [520, 1032)   the committed cursors, [8][64]
-//   words [1032, 1096)  the permutation: o1 | o2 << 8 per lane
-//   words [1096, ...)   PbCarry: the search state (sums <= lo are visited) and the frame's scalars
+//   words [0, 524)      the frame's tables as they stand in PbWaveLds (pad, w, P, cdfA, tail, tq), verbatim
+//   words [524, 1036)   the committed cursors, [8][64]
+//   words [1036, 1068)  the permutation, one byte per primed position (as in the singles record)
+//   words [1068, ...)   PbCarry: the search state (sums <= lo are visited) and the frame's scalars
 struct PbCarry {
     float lo, best;
     int j, nlive, cmp, suc1, suc2, bestidx;
@@ -1295,26 +1384,24 @@ struct PbCarry {
     long long f;
     float tprev, nprev;      // the last chunk's lower bound and the TEPs before it (the growth exponent for the next bound)
 };
-constexpr int kPbRecPrefix = 520, kPbRecCur = 520, kPbRecPerm = 1032, kPbRecScalars = 1096, kPbRecWords = 1152;
+constexpr int kPbRecPrefix = 524, kPbRecCur = 524, kPbRecPerm = 1036, kPbRecScalars = 1068, kPbRecWords = 1120;
 static_assert(kPbRecScalars * 4 % 8 == 0 && kPbRecScalars * 4 + sizeof(PbCarry) <= kPbRecWords * 4, "record layout");
 static_assert(offsetof(PbWaveLds<kPbWaveCap>, cdfH) == kPbRecPrefix * 4, "the record's first part is the head of PbWaveLds");
 
 // One frame of list A per wavefront, from its first TEP to its stop (or to the end of the table); massive ties go to
 // list B (list replay).  Workgroup b serves sub-list b mod 16, entries b / 16, b / 16 + grid / 16, ...
 // (12 KiB of LDS per frame: 13 workgroups per CU; three wavefronts per SIMD asked of the register allocator)
-template <int CAP, bool PROF>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb_wave_kernel(const float *__restrict__ y, const int *__restrict__ index,
-                                                     const unsigned char *__restrict__ perm_in,
-                                                     const u64 *__restrict__ parity_in, PbParams P,
+template <int CAP, bool PROF, int ROT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb_wave_kernel(PbParams P,
                                                      const double *__restrict__ cdf_half, int *__restrict__ ctl,
                                                      const int *__restrict__ listA, int *__restrict__ listB, int sub_cap,
                                                      unsigned *__restrict__ carry,
-                                                     const PbPrep *__restrict__ prep, PbOut O, unsigned long long *__restrict__ prof_out)
+                                                     const unsigned *__restrict__ recs, PbOut O, unsigned long long *__restrict__ prof_out)
 {
     __shared__ PbWaveLds<CAP> L;
     unsigned long long pt[kPwSlots] = {0}, plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
-    const int lane = threadIdx.x;
+    const int lane0 = threadIdx.x;
     const int sub = blockIdx.x & (kPbSub - 1);
     const int len = ctl[kPbCtlLenA + kPbCtlLine * sub];
     const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);      // TEPs of weight 1..order
@@ -1323,33 +1410,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
     const int budget0 = len < 128 ? P.budget_s : (len < 448 ? P.budget_m : (len < 1400 ? P.budget : (len < 3000 ? P.budget_l : P.budget_xl)));
     bool have_cdfh = false;
     for (int k = blockIdx.x >> 4; k < len; k += gridDim.x >> 4) {
+        // (an opaque copy of the lane number per frame: otherwise every lane-dependent constant of the frame's code -- item
+        //  geometry, the rank sort's tie masks -- is hoisted out of this loop, kept in registers for the whole kernel and spilled)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
         if (!have_cdfh) {
             L.cdfH[lane] = (float)cdf_half[lane];
             if (lane == 0) L.cdfH[64] = (float)cdf_half[64];
+            if (lane < 4) L.pre[lane] = pbw_nan();
             have_cdfh = true;
         }
         // (a frame that starts late -- its workgroup waited for a slot -- would end the launch if it ran long here: it leaves sooner)
         const int budget = (len * kPbSub > P.late_min && len < P.late_maxlen && k * 100 >= len * P.late_pct) ? budget0 / P.late_div : budget0;
         const long long f = listA[sub * sub_cap + k];
-        const long long src = index ? index[f] : f;
-        if constexpr (PROF) { long long t = src; asm volatile("s_waitcnt vmcnt(0)" : "+v"(t)); PBW_STAMP(kPwLoad1); }
-        // ---- per-frame set-up (search_prepare): primed-order values, hard decisions, byte LUTs, order-0 discrepancy
-        const int o1 = perm_in[f * 128 + lane], o2 = perm_in[f * 128 + 64 + lane];
-        const u64 Prow = parity_in[f * 64 + lane];
-        const float y1 = y[src * 128 + o1], y2 = y[src * 128 + o2];
-        PbFrame Fr;
-        if (prep) {   // what pb_singles_kernel already computed for this frame
-            const PbPrep &R = prep[f];
-            const float qp = R.q[64 + lane];
-            L.tq[lane] = make_float2(2.0f * (1.0f - qp), 2.0f * qp);
-            L.cdfA[lane] = (float)R.cdfA[lane];
-            if (lane == 0) L.cdfA[64] = (float)R.cdfA[64];
-            Fr = R.fr;
+        // ---- per-frame set-up: ONE wide load of the record pb_singles_kernel wrote (P', |y'|, the CDF table: 324 words, copied
+        // into LDS as they are), the frame's scalars by scalar loads; derived here: the cost-bound table, the success-rule factors
+        const unsigned *const rec = recs + f * kPbR1Words;
+        {
+            const uint4 *const r4 = reinterpret_cast<const uint4 *>(rec);
+            uint4 *const l4 = reinterpret_cast<uint4 *>(L.w);
+            const uint4 a = r4[lane];
+            uint4 b = make_uint4(0, 0, 0, 0);
+            if (lane < 17) b = r4[64 + lane];
+            if constexpr (PROF) { unsigned t = a.x; asm volatile("s_waitcnt vmcnt(0)" : "+v"(t)); PBW_STAMP(kPwLoad1); }
+            l4[lane] = a;
+            if (lane < 17) l4[64 + lane] = b;
         }
-        L.w[lane] = __builtin_fabsf(y1);
-        L.w[lane + 64] = __builtin_fabsf(y2);
-        L.P[lane] = Prow;
-        const u64 hm = __ballot(!(y1 > 0.0f)), hp = __ballot(!(y2 > 0.0f));
+        const PbHead &H = *reinterpret_cast<const PbHead *>(rec + kPbR1Head);
+        const PbFrame Fr = H.fr;
+        const u64 d0 = H.d0;
         wave_fence();
         PBW_STAMP(kPwLoad2);
         {   // pbw_cost_floor's table: every quarter's 16 parity weights in ascending order (rank sort inside the 16-lane row,
@@ -1361,6 +1450,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
             for (int u = 0; u < 16; ++u) { const float o = L.w[64 + g0 + u]; r += (o < v) || (o == v && g0 + u < lane); }
             float *const srt = reinterpret_cast<float *>(L.keys);
             srt[g0 + r] = v;
+            const float qp = 1.0f / (1.0f + det_expf(-(P.c4 * v)));          // sigmoid(c4 |y'_p|), as pb_frame_setup computes it
+            L.tq[lane] = make_float2(2.0f * (1.0f - qp), 2.0f * qp);        // pb_success_terms
             wave_fence();
             float acc = srt[lane];
             acc = acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111, 0xF, 0xF, true));   // row_shr:1,2,4,8:
@@ -1370,35 +1461,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
             L.tail[lane >> 4][(lane & 15) + 1] = acc * 0.99999f;
             if ((lane & 15) == 0) L.tail[lane >> 4][0] = 0.0f;
         }
-        const u64 d0 = wave_xor64(((hm >> lane) & 1) ? Prow : 0ull) ^ hp;
         wave_fence();
         PbwState S;
-        S.best = prep ? prep[f].hbest : tep_cost_direct_uniform(L.w, 0.0f, d0, lane);     // (the order-0 metric, or what the head made of it)
+        S.best = H.hbest;        // (the order-0 metric, or what the head made of it)
         S.j = 0; S.nlive = 1; S.cmp = 0; S.suc1 = 0; S.suc2 = 0; S.bestidx = 0; S.bestD = d0; S.bestE = 0;
-        if (!prep) {  // cross-check route (every frame from its first TEP): the frame quantities are computed here
-            float *q = reinterpret_cast<float *>(L.keys);
-            double *cdf64 = reinterpret_cast<double *>(L.keys) + 64;
-            Fr = pb_frame_setup(L.w, q, cdf64, P.c4, P.order, P.nmax, lane, S.best);
-            pb_success_terms(q, L.tq, lane);
-            L.cdfA[lane] = (float)cdf64[lane];
-            if (lane == 0) L.cdfA[64] = (float)cdf64[64];
-            wave_fence();
-        }
         PbWalk W;
         pbw_walk_init<CAP>(L, W, P.order, lane);
         float lo = -1.0f;
         int done = 0;
-        if (prep) {   // go on where pb_singles_kernel stopped: the nhead least reliable singles are visited (every other sum is larger)
-            const PbPrep &R = prep[f];
-            const int nh = R.nhead;
+        {   // go on where pb_singles_kernel stopped: the nhead least reliable singles are visited (every other sum is larger)
+            const int nh = H.nhead;
             if (nh > 0) {
-                S.j = nh; S.nlive = nh; S.cmp = 2 * nh - (nh < 2 ? nh : 2); S.suc1 = nh; S.suc2 = R.hsuc2;
-                if (R.hsuc2 > 0) { S.best = R.hbest; S.bestidx = R.hbestidx; S.bestD = R.hbestD; S.bestE = R.hbestE; }
+                S.j = nh; S.nlive = nh; S.cmp = 2 * nh - (nh < 2 ? nh : 2); S.suc1 = nh; S.suc2 = H.hsuc2;
+                if (H.hsuc2 > 0) { S.bestidx = H.hbestidx; S.bestD = H.hbestD; S.bestE = H.hbestE; }
                 lo = L.w[64 - nh]; done = nh;
-                if (lane == 63) {   // the singles are item 31 of lane 63: cursor and next member
+                if (lane == 63)     // the singles are item 31 of lane 63: its cursor
                     W.ecur[7] = (W.ecur[7] & 0x00FFFFFFu) | ((unsigned)(64 - nh) << 24);
-                    W.nxt[31] = nh < 64 ? L.w[63 - nh] : pbw_nan();
-                }
                 L.cur[7][lane] = W.ecur[7];
             }
         }
@@ -1410,7 +1488,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
         while (state == 0 && done < nall) {
             float T;
             int nwalks = 0;
-            const int n = pbw_next_chunk<CAP, PROF>(L, W, P.order, lo, done, nall, done == 0 ? P.t1 : P.t2, lane, T, tprev, nprev, nwalks, pt);
+            const int n = pbw_next_chunk<CAP, PROF, ROT>(L, W, P.order, lo, done, nall, done == 0 ? P.t1 : P.t2, lane, T, tprev, nprev, nwalks, pt);
             PBW_STAMP(kPwWalk);
             if constexpr (PROF) { pt[kPwChunks] += 1; pt[kPwWalks] += nwalks; pt[kPwKeys] += n > 0 ? n : 0; }
             if (n < 0) { state = 2; break; }
@@ -1421,7 +1499,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
             PBW_STAMP(kPwScan);
             if (state < 0) {
                 if constexpr (PROF) pt[kPwSorted] += 1;
-                state = pbw_process_chunk<CAP, PROF>(L, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep, pt, plast);
+                state = pbw_sorted_call<CAP>(L, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep);
+                pbw_cursors_load<CAP>(L, W.ecur, lane);        // (not kept across the call: L.cur holds the committed cursors)
             }
             lo = T;
             done += n;
@@ -1432,18 +1511,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
                 if (lane == 0) slot = atomicAdd(&ctl[kPbCtlLenC], 1);
                 slot = __builtin_amdgcn_readfirstlane(slot);
                 if (slot < kPbHeavyCap) {
-                    unsigned *const rec = carry + (long long)slot * kPbRecWords;
+                    unsigned *const crec = carry + (long long)slot * kPbRecWords;
                     const unsigned *const Lw = reinterpret_cast<const unsigned *>(&L);
-                    for (int k = lane; k < kPbRecPrefix; k += 64) rec[k] = Lw[k];
+                    for (int k = lane; k < kPbRecPrefix; k += 64) crec[k] = Lw[k];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) rec[kPbRecCur + k * 64 + lane] = W.ecur[k];
-                    rec[kPbRecPerm + lane] = (unsigned)o1 | ((unsigned)o2 << 8);
+                    for (int k = 0; k < 8; ++k) crec[kPbRecCur + k * 64 + lane] = W.ecur[k];
+                    if (lane < 32) crec[kPbRecPerm + lane] = rec[kPbR1Perm + lane];
                     if (lane == 0) {
                         PbCarry c;
                         c.lo = lo; c.best = S.best; c.j = S.j; c.nlive = S.nlive; c.cmp = S.cmp; c.suc1 = S.suc1; c.suc2 = S.suc2;
                         c.bestidx = S.bestidx; c.bestD = S.bestD; c.bestE = S.bestE;
-                        c.fr = Fr; c.d0 = d0; c.hm = hm; c.hp = hp; c.f = f; c.tprev = tprev; c.nprev = nprev;
-                        *reinterpret_cast<PbCarry *>(rec + kPbRecScalars) = c;
+                        c.fr = Fr; c.d0 = d0; c.hm = H.hm; c.hp = H.hp; c.f = f; c.tprev = tprev; c.nprev = nprev;
+                        *reinterpret_cast<PbCarry *>(crec + kPbRecScalars) = c;
                     }
                     state = 3;
                 }
@@ -1458,7 +1537,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
         {   // candidate (E = flipped MRB positions, D = parity discrepancy) -> codeword in ORIGINAL bit order
             if (lane < 2) L.cw[lane] = 0;
             wave_fence();
-            const u64 mrb_bits = hm ^ S.bestE, par_bits = S.bestD ^ hp;
+            const unsigned char *const pb = reinterpret_cast<const unsigned char *>(rec + kPbR1Perm);
+            const int o1 = pb[lane], o2 = pb[64 + lane];       // (original bit index of primed positions lane, 64 + lane)
+            const u64 mrb_bits = H.hm ^ S.bestE, par_bits = S.bestD ^ H.hp;
             if ((mrb_bits >> lane) & 1) atomicOr(&L.cw[o1 >> 6], 1ull << (o1 & 63));
             if ((par_bits >> lane) & 1) atomicOr(&L.cw[o2 >> 6], 1ull << (o2 & 63));
             wave_fence();
@@ -1475,7 +1556,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
         PBW_STAMP(kPwStore);
         if constexpr (PROF) pt[kPwFrames] += 1;
     }
-    if constexpr (PROF) { if (lane == 0 && pt[kPwFrames]) for (int k = 0; k < kPwSlots; ++k) atomicAdd(&prof_out[k], pt[k]); }
+    if constexpr (PROF) { if (lane0 == 0 && pt[kPwFrames]) for (int k = 0; k < kPwSlots; ++k) atomicAdd(&prof_out[k], pt[k]); }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1576,27 +1657,6 @@ __device__ __forceinline__ void coop_item(int v, int j, int lane, int &q, int &l
     static_assert(NW == 16, "the dealing is written for sixteen wavefronts");
     q = 16 * j + (lane >> 2);
     l = ((13 * (v - 3 * q)) & 15) + 16 * (lane & 3);        // 5 l = v - 3 q (mod 16), 5 * 13 = 1
-}
-
-__device__ __forceinline__ PbwItem pbw_item_rt(int q, int l)
-{
-    PbwItem it;
-    const bool tri = q < 31, first = l < 62 - q;
-    it.i = tri ? (first ? q : 61 - q) : l;
-    it.j = tri ? (first ? q + 1 + l : l) : l;
-    it.base = tri ? (l <= 62 ? it.j : 63) : (l <= 62 ? l : -1);
-    it.code = tri ? ((3u << 24) | ((unsigned)it.j << 8) | (unsigned)it.i) : (l <= 62 ? ((2u << 24) | (unsigned)l) : (1u << 24));
-    it.sh = tri ? 16 : (l <= 62 ? 8 : 0);
-    return it;
-}
-// sum of the next member of item (q, l) whose cursor is a (members [a, 64) are visited); NaN: none left
-__device__ __forceinline__ float pbw_next_sum(const float *w, int q, int l, int a, int order)
-{
-    const PbwItem it = pbw_item_rt(q, l);
-    const bool live = a > it.base + 1 && (q < 31 ? order > 2 : (order > 1 || l == 63));
-    const float sb = q < 31 ? w[it.i] + w[it.j] : (l <= 62 ? w[l] : 0.0f);
-    const float s = sb + w[a > 0 ? a - 1 : 0];
-    return live ? s : pbw_nan();
 }
 
 // A wavefront's items in registers: item j of this lane is (row q, lane l) = coop_item(v, j, lane); sb = the sum of its fixed
@@ -2023,19 +2083,6 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
     return 0;
 }
 
-// nxt of all 32 rows from the cursors in L.cur (a wavefront that takes a search over in the middle)
-template <int CAP>
-__device__ __forceinline__ void pbw_walk_resume(PbWaveLds<CAP> &L, PbWalk &W, int order, int lane)
-{
-    pbw_cursors_load<CAP>(L, W.ecur, lane);
-#pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        float v = pbw_next_sum(L.w, q, lane, (int)((W.ecur[q >> 2] >> (8 * (q & 3))) & 255u), order);
-        asm volatile("" : "+v"(v) : : "memory");
-        W.nxt[q] = v;
-    }
-}
-
 // Wavefront 0 alone over the sums (lo, T] that hold n TEPs: the sorted path, in sub-chunks.  L.one.cur holds the cursors of
 // the range's start (all 32 rows); arguments in L.su / L.bs / L.sP, results in L.bs / L.bstate / L.bstop / L.bntep
 // (state 0 / 1 / 2 as in pb_wave_kernel).
@@ -2057,18 +2104,18 @@ __device__ __noinline__ void coop_solo_range(PbCoopLds<NW> &L)
     int stop = L.bstop, ntep = L.bntep;
     wave_fence();
     PbWalk W;
-    pbw_walk_resume<CAP>(L.one, W, P.order, lane);
+    pbw_cursors_load<CAP>(L.one, W.ecur, lane);     // (the walk needs nothing but the cursors)
     float tprev = 0.0f, nprev = 0.0f;
     int state = 0;
     while (state == 0 && done < end) {
         float T;
         int nwalks = 0;
-        const int n = pbw_next_chunk<CAP, false>(L.one, W, P.order, lo, done, nall, P.t2, lane, T, tprev, nprev, nwalks, pt, Tcap);
+        const int n = pbw_next_chunk<CAP, false, 0>(L.one, W, P.order, lo, done, nall, P.t2, lane, T, tprev, nprev, nwalks, pt, Tcap);
         if (n <= 0) { state = 2; break; }
         wave_fence();
         const float cmn = lo < 0.0f ? L.one.w[63] : lo, cmx = T < __builtin_inff() ? T : smax;
         state = pbw_scan_chunk<CAP>(L.one, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep);
-        if (state < 0) state = pbw_process_chunk<CAP, false>(L.one, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep, pt, plast);
+        if (state < 0) { state = pbw_sorted_call<CAP>(L.one, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep); pbw_cursors_load<CAP>(L.one, W.ecur, lane); }
         lo = T;
         done += n;
     }
@@ -2111,7 +2158,7 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
         // the frame's tables: one load per thread (wavefront 0 may still be writing the previous frame's codeword out)
         if (tid >= 64 && tid < 64 + kPbRecPrefix) reinterpret_cast<unsigned *>(&L.one)[tid - 64] = rec[tid - 64];
         const PbCarry &c = *reinterpret_cast<const PbCarry *>(rec + kPbRecScalars);
-        unsigned po = wave == 0 ? rec[kPbRecPerm + lane] : 0u;      // (the permutation, for the codeword at the end: in flight from here)
+        unsigned po = wave == 0 ? rec[kPbRecPerm + (lane >> 2)] : 0u, po2 = wave == 0 ? rec[kPbRecPerm + 16 + (lane >> 2)] : 0u;      // (the permutation, for the codeword at the end: in flight from here)
         PbFrame Fr = c.fr;
         u64 d0 = c.d0;
         PbwState S;
@@ -2157,7 +2204,8 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
                 for (int j = 0; j < NI; ++j) {
                     int q, l;
                     coop_item<NW>(wave, j, lane, q, l);
-                    reinterpret_cast<unsigned char *>(&L.one.cur[q >> 2][l])[q & 3] = (unsigned char)aprev[j];
+                    // (the chunk kernel's code marks an item without members by a cursor of 0; here the cursor stops at base + 1)
+                    reinterpret_cast<unsigned char *>(&L.one.cur[q >> 2][l])[q & 3] = (unsigned char)(aprev[j] > I.base[j] + 1 ? aprev[j] : 0);
                 }
                 __syncthreads();
                 if (wave == 0) {
@@ -2178,7 +2226,7 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
                     Fr = L.su.fr; d0 = L.su.d0; lo = L.su.lo; T = L.su.T; tprev = L.su.tprev; nprev = L.su.nprev; smax = L.su.smax;
                     done = L.su.done; n = L.su.n; R.seq = L.su.seq; R.par = L.su.par; it = L.su.it; tk = L.su.tk;
                     rec = carry + (long long)tk * kPbRecWords;
-                    po = rec[kPbRecPerm + lane];
+                    po = rec[kPbRecPerm + (lane >> 2)]; po2 = rec[kPbRecPerm + 16 + (lane >> 2)];
                     next_tk = L.su.next_tk;
                 }
                 __syncthreads();
@@ -2197,7 +2245,7 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
                 const PbCarry &c2 = *reinterpret_cast<const PbCarry *>(rec + kPbRecScalars);
                 const u64 hm = c2.hm, hp = c2.hp;
                 const long long f = c2.f;
-                const int o1 = (int)(po & 255u), o2 = (int)(po >> 8);
+                const int o1 = (int)((po >> (8 * (lane & 3))) & 255u), o2 = (int)((po2 >> (8 * (lane & 3))) & 255u);
                 if (lane < 2) L.one.cw[lane] = 0;
                 wave_fence();
                 const u64 mrb_bits = hm ^ S.bestE, par_bits = S.bestD ^ hp;
@@ -2453,7 +2501,7 @@ static int stream_ws_pb(ldpc_ctx *ctx, hipStream_t s, int64_t frames, int64_t sp
         const int64_t sub_cap = (frames + kPbSub - 1) / kPbSub;
         if (hipMalloc((void **)&w.d_pb_list, sizeof(int) * (2 * (size_t)kPbSub * (size_t)sub_cap)) != hipSuccess ||
             hipMalloc(&w.d_pb_carry, sizeof(unsigned) * kPbRecWords * (size_t)kPbHeavyCap) != hipSuccess ||
-            hipMalloc(&w.d_pb_prep, sizeof(PbPrep) * (size_t)frames) != hipSuccess)
+            hipMalloc(&w.d_pb_prep, sizeof(unsigned) * kPbR1Words * (size_t)frames) != hipSuccess)
             return fail(LDPC_E_NOMEM, "PB-OSD frame lists for %lld frames could not be allocated", (long long)frames);
         w.pb_cap = frames; w.pb_sub_cap = sub_cap;
     }
@@ -2525,20 +2573,20 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     int *listA = w->d_pb_list, *listB = w->d_pb_list + list_len;
     unsigned *carry = reinterpret_cast<unsigned *>(w->d_pb_carry);      // [kPbHeavyCap] records of kPbRecWords words
     const int sub_cap = (int)w->pb_sub_cap;
-    PbPrep *prep_w = reinterpret_cast<PbPrep *>(w->d_pb_prep);
+    unsigned *recs = reinterpret_cast<unsigned *>(w->d_pb_prep);      // [pb_cap] records of kPbR1Words words (singles -> chunk kernel)
     hipLaunchKernelGGL(pb_ctl_clear_kernel, dim3(1), dim3(64), 0, s, w->d_pb_ctl);
     const int64_t want = (F + 3) / 4;
     const unsigned g1 = (unsigned)(F < 1 ? 1 : (F < 32768 ? F : 32768));
     static const bool profile_s = getenv("LDPC_PB_PROFILE") != nullptr;
     if (!profile_s) {
         hipLaunchKernelGGL(pb_singles_kernel<false>, dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
-                           st->d_cdf_half, w->d_pb_ctl, listA, listB, sub_cap, prep_w, O, (unsigned long long *)nullptr);
+                           st->d_cdf_half, w->d_pb_ctl, listA, listB, sub_cap, recs, O, (unsigned long long *)nullptr);
     } else {
         static unsigned long long *d_ps = nullptr;
         if (!d_ps) LDPC_HIP(hipMalloc((void **)&d_ps, sizeof(unsigned long long) * 8));
         LDPC_HIP(hipMemsetAsync(d_ps, 0, sizeof(unsigned long long) * 8, s));
         hipLaunchKernelGGL(pb_singles_kernel<true>, dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
-                           st->d_cdf_half, w->d_pb_ctl, listA, listB, sub_cap, prep_w, O, d_ps);
+                           st->d_cdf_half, w->d_pb_ctl, listA, listB, sub_cap, recs, O, d_ps);
         unsigned long long h[8];
         LDPC_HIP(hipMemcpyAsync(h, d_ps, sizeof(h), hipMemcpyDeviceToHost, s));
         LDPC_HIP(hipStreamSynchronize(s));
@@ -2547,18 +2595,28 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     }
     // chunk kernel: one workgroup (= one wavefront) per (sub-list, entry); a multiple of 16 workgroups, at most 65 536 (a
     // workgroup then takes every 4096th entry of its sub-list).  Workgroups beyond their sub-list's length leave at once.
+    // (three instantiations by what the context's probe of the wave_rol:1 DPP control found -- the walk rotates a copy of the
+    //  weights through the wavefront: -1 = a lane receives its upper neighbour's value, +1 = its lower neighbour's, 0 = not a
+    //  rotation: LDS reads instead)
+    const int rot = ctx->dpp_wave_rol_dir;
+#define PB_WAVE_LAUNCH(PROFILED, prof_ptr)                                                                                           \
+    do {                                                                                                                             \
+        if (rot < 0) hipLaunchKernelGGL((pb_wave_kernel<kPbWaveCap, PROFILED, -1>), dim3(g2), dim3(64), 0, s, pp, st->d_cdf_half, w->d_pb_ctl, \
+                                        listA, listB, sub_cap, carry, recs, O, prof_ptr);                                            \
+        else if (rot > 0) hipLaunchKernelGGL((pb_wave_kernel<kPbWaveCap, PROFILED, 1>), dim3(g2), dim3(64), 0, s, pp, st->d_cdf_half, w->d_pb_ctl, \
+                                             listA, listB, sub_cap, carry, recs, O, prof_ptr);                                       \
+        else hipLaunchKernelGGL((pb_wave_kernel<kPbWaveCap, PROFILED, 0>), dim3(g2), dim3(64), 0, s, pp, st->d_cdf_half, w->d_pb_ctl, \
+                                listA, listB, sub_cap, carry, recs, O, prof_ptr);                                                    \
+    } while (0)
     const int64_t g2w = ((F + kPbSub - 1) / kPbSub) * kPbSub;
     const unsigned g2 = (unsigned)(g2w < 65536 ? g2w : 65536);
-    const PbPrep *prep = mode == 0 ? prep_w : nullptr;    // (cross-check routes skip the stage that fills it)
     if (!profile_s) {
-        hipLaunchKernelGGL((pb_wave_kernel<kPbWaveCap, false>), dim3(g2), dim3(64), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half, w->d_pb_ctl,
-                           listA, listB, sub_cap, carry, prep, O, (unsigned long long *)nullptr);
+        PB_WAVE_LAUNCH(false, (unsigned long long *)nullptr);
     } else {
         static unsigned long long *d_pw = nullptr;
         if (!d_pw) LDPC_HIP(hipMalloc((void **)&d_pw, sizeof(unsigned long long) * kPwSlots));
         LDPC_HIP(hipMemsetAsync(d_pw, 0, sizeof(unsigned long long) * kPwSlots, s));
-        hipLaunchKernelGGL((pb_wave_kernel<kPbWaveCap, true>), dim3(g2), dim3(64), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half, w->d_pb_ctl,
-                           listA, listB, sub_cap, carry, prep, O, d_pw);
+        PB_WAVE_LAUNCH(true, d_pw);
         unsigned long long h[kPwSlots];
         LDPC_HIP(hipMemcpyAsync(h, d_pw, sizeof(h), hipMemcpyDeviceToHost, s));
         LDPC_HIP(hipStreamSynchronize(s));
@@ -2567,6 +2625,7 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
         for (int q = 0; q < kPwSlots; ++q) fprintf(stderr, " %s=%llu", names[q], h[q]);
         fprintf(stderr, "\n");
     }
+#undef PB_WAVE_LAUNCH
     // the long searches the chunk kernel handed on (at most kPbHeavyCap; the workgroups find an empty list otherwise)
     const unsigned g4 = (unsigned)(F < kPbCoopGrid ? F : kPbCoopGrid);
     if (!profile_s) {

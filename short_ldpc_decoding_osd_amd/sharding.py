@@ -41,7 +41,8 @@ def end_to_end_errors(counters, with_osd: bool) -> int:
     return c[6] + c[3] if with_osd else c[1]
 
 
-def sweep_point(decode_batch, frames_mine: int, batch: int, max_batches: int, stop_errors: int = 0, with_osd: bool = True):
+def sweep_point(decode_batch, frames_mine: int, batch: int, max_batches: int, stop_errors: int = 0, with_osd: bool = True,
+                device=None):
     """The macro-batch loop of ONE SNR point on one rank, with the reference's stop rule.
 
     ``decode_batch(B)`` decodes the next B frames of this rank's shard and returns their int64[8] counters
@@ -56,7 +57,14 @@ def sweep_point(decode_batch, frames_mine: int, batch: int, max_batches: int, st
     the point ends as soon as the end-to-end frame errors of ALL ranks together reach N.  All ranks see the same sums, so
     they leave on the same macro-batch, and the returned totals are those of the frames actually decoded.
 
+    ``device``: where this rank's counters live (the rank's GPU under the ``nccl`` backend -- RCCL cannot reduce a CPU tensor,
+    and a rank whose shard is EMPTY never gets a tensor from ``decode_batch`` to copy the device from; default: CPU, which
+    is what the gloo tests use).
+
     Returns (reduced int64[8] totals, macro-batches run)."""
+    def zeros():
+        return torch.zeros(8, dtype=torch.int64, device=device)
+
     total = None
     done = 0
     ran = 0
@@ -68,13 +76,13 @@ def sweep_point(decode_batch, frames_mine: int, batch: int, max_batches: int, st
         done += max(B, 0)
         ran += 1
         if stop_errors > 0:
-            cur = total.clone() if total is not None else torch.zeros(8, dtype=torch.int64)
+            cur = total.clone() if total is not None else zeros()
             red = allreduce_counters(cur)
             if end_to_end_errors(red.tolist(), with_osd) >= stop_errors:
                 return red, ran
     if stop_errors > 0:
         return red, ran
-    return allreduce_counters(total if total is not None else torch.zeros(8, dtype=torch.int64)), ran
+    return allreduce_counters(total if total is not None else zeros()), ran
 
 
 def combine_fer(counters) -> dict:

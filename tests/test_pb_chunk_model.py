@@ -135,8 +135,8 @@ def _items():
             if q < 31:
                 if l == 63:
                     continue                                   # lane 63 owns no triple item
-                first = l < 62 - q
-                i, j = (q, q + 1 + l) if first else (61 - q, l)
+                first = l < 62 - q                             # rows by the distance of the two fixed positions (round 4)
+                i, j = (l, l + 1 + q) if first else (l - 62 + q, l)
                 out[(q, l)] = ((i, j), j)
             else:
                 out[(q, l)] = ((l,), l) if l <= 62 else ((), -1)   # the pairs of i = l; lane 63: the singles

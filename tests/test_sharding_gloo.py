@@ -209,6 +209,47 @@ def test_world2_stop_rule(stop_errors):
         assert red0[0] == total
 
 
+def _empty_shard_worker(rank, world, port, stop_errors, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from short_ldpc_decoding_osd_amd.sharding import shard_range, sweep_point
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = 1                                              # fewer frames than ranks: rank 1's shard is empty
+    lo, hi = shard_range(total, rank, world)
+    calls = []
+
+    def decode_batch(B):
+        calls.append(B)
+        return torch.tensor([B, 1, 3, 0, 1, 1, 1, 7], dtype=torch.int64)
+
+    red, ran = sweep_point(decode_batch, hi - lo, 4, 1, stop_errors, with_osd=True, device=torch.device("cpu"))
+    out.put((rank, ran, red.tolist(), calls, str(red.device)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stop_errors", [0, 1])
+def test_world2_rank_with_an_empty_shard(stop_errors):
+    """--frames smaller than the world size: the rank without frames never calls decode_batch, contributes zero counters
+    allocated on the device it was given (under nccl a CPU tensor cannot be reduced) and leaves with the others."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_shard_worker, args=(r, 2, port, stop_errors, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, ran0, red0, calls0, dev0), (_, ran1, red1, calls1, dev1) = got
+    assert calls0 == [1] and calls1 == []
+    assert ran0 == ran1 == 1 and red0 == red1 == [1, 1, 3, 0, 1, 1, 1, 7]
+    assert dev0 == dev1 == "cpu"
+
+
 # ---------------------------------------------------------------------------------------------------------
 # bench.py's own rank launcher (no GPU call in the parent; dummy workers)
 # ---------------------------------------------------------------------------------------------------------
