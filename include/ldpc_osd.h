@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LDPC_OSD_ABI_VERSION 3
+#define LDPC_OSD_ABI_VERSION 4
 
 enum {
     LDPC_OK = 0,
@@ -199,13 +199,39 @@ typedef struct ldpc_osd_params {
                             [0, y_frames) replaced by 0) and count the offenders, see ldpc_osd_index_errors           */
 } ldpc_osd_params;
 
+/* PB-OSD tuning of a context (ABI 4; rounds 1-3 read these from LDPC_PB_* environment variables on every call).
+ * None of it changes a result -- TEP counts, stop reasons, winners and metrics are the same for every setting (the
+ * tests run the kernels under several) -- only how the searches of pb_osd (PB_OSD/pb_testing.py:100-149) are cut into
+ * chunks and when a long search moves from the one-wavefront kernel to the one-workgroup kernel:
+ *   budget_s / budget_m / budget / budget_l / budget_xl
+ *                  TEPs after which a search may be handed to the workgroup kernel, chosen on the device by the number of
+ *                  frames still searching after the weight-1 head (a sixteenth of them: < 128 / < 448 / < 1400 / < 3000 /
+ *                  more); >= 1.  Defaults 512 / 1024 / 4096 / 8192 / 24576 (measurements: DESIGN.md 3.4).
+ *   t1, t2         target size of a frame's first / later chunks in the one-wavefront kernel, 32..384 (320, 312)
+ *   t3             target chunk size of the workgroup kernel, 256..4096 (3072)
+ *   late_min, late_maxlen, late_pct, late_div
+ *                  frames beyond late_pct % of their sub-list (lists of more than late_min and fewer than late_maxlen
+ *                  frames) leave after budget / late_div TEPs; late_pct = 1000 (the default) switches this off
+ *   handoff_maxlen no search is handed on when the sub-list holds this many frames or more (default 2^30)
+ * ldpc_ctx_set_pb_tuning validates (LDPC_E_ARG, nothing changed) and stores a copy; NULL restores the defaults.  It
+ * applies to decode calls ISSUED afterwards (a captured graph keeps the values it was captured with); call it from
+ * one thread, not concurrently with decode calls that should see a particular setting.                            */
+typedef struct ldpc_pb_tuning {
+    int32_t budget, budget_s, budget_m, budget_l, budget_xl;
+    int32_t t1, t2, t3;
+    int32_t late_min, late_maxlen, late_pct, late_div;
+    int32_t handoff_maxlen;
+} ldpc_pb_tuning;
+int ldpc_ctx_get_pb_tuning(ldpc_ctx *ctx, ldpc_pb_tuning *out);
+int ldpc_ctx_set_pb_tuning(ldpc_ctx *ctx, const ldpc_pb_tuning *tuning);
+
 /* Pre-size OSD workspaces (640 B per frame: permutation + reduced parity rows) for up to max_frames
  * frames per ldpc_osd_decode call: ldpc_osd_reserve sizes the NULL stream's workspace immediately and every
  * other stream's when it is created.  Decode calls grow their stream's workspace on demand, which allocates
  * -- so before capturing calls on a stream into a hipGraph, size that stream's workspace with
  * ldpc_osd_reserve_stream: params = NULL sizes the front-end workspace only; with params it also sizes what
- * the search of (params->algo, params->order) needs (PB-OSD: frame lists, per-frame tables, list-replay
- * areas, ~1.1 KiB per frame + 180 MB), so that the FIRST call on the stream may be the captured one.
+ * the search of (params->algo, params->order) needs (PB-OSD: frame lists, one 1536-byte record per frame, list-replay
+ * areas, ~1.5 KiB per frame + 180 MB), so that the FIRST call on the stream may be the captured one.
  * ldpc_osd_release_stream frees the workspace of `stream` (idle, not capturing; graphs captured on it must
  * not be launched afterwards) -- for destroyed streams, whose handle the runtime may hand out again.     */
 int ldpc_osd_reserve(ldpc_ctx *ctx, int64_t max_frames);

@@ -18,7 +18,7 @@ SYMBOLS = (
     "ldpc_last_error", "ldpc_abi_version",
     "ldpc_code_from_alist", "ldpc_code_from_dense", "ldpc_code_destroy", "ldpc_code_dims",
     "ldpc_code_get_H", "ldpc_code_get_G", "ldpc_gf2elim_host", "ldpc_tep_table", "ldpc_tep_table_fs", "ldpc_crc32c",
-    "ldpc_ctx_create", "ldpc_ctx_destroy", "ldpc_ctx_nms_kernel",
+    "ldpc_ctx_create", "ldpc_ctx_destroy", "ldpc_ctx_nms_kernel", "ldpc_ctx_get_pb_tuning", "ldpc_ctx_set_pb_tuning",
     "ldpc_nms_decode", "ldpc_eval_counts", "ldpc_compact", "ldpc_pack_bits", "ldpc_unpack_bits",
     "ldpc_osd_reserve", "ldpc_osd_reserve_stream", "ldpc_osd_release_stream", "ldpc_osd_index_errors", "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_search", "ldpc_osd_decode", "ldpc_osd_tep_eval", "ldpc_osd_counts",
     "ldpc_hosd_pattern_teps", "ldpc_hosd_front", "ldpc_hosd_search",
@@ -33,6 +33,12 @@ class OsdParams(C.Structure):
     _fields_ = [("order", C.c_int32), ("algo", C.c_int32), ("snr_db", C.c_float), ("fs_beta", C.c_float),
                 ("fs_tau_e", C.c_float), ("fs_tau_psc", C.c_float), ("fs_reference_quirk", C.c_int32),
                 ("reserved", C.c_int32), ("d_aux", C.c_void_p), ("y_frames", C.c_int64)]
+
+
+class PbTuning(C.Structure):
+    """ldpc_pb_tuning of include/ldpc_osd.h (PB-OSD hand-over schedule and chunk targets of a context)."""
+    _fields_ = [(n, C.c_int32) for n in ("budget", "budget_s", "budget_m", "budget_l", "budget_xl", "t1", "t2", "t3",
+                                         "late_min", "late_maxlen", "late_pct", "late_div", "handoff_maxlen")]
 
 
 class Pipeline(C.Structure):
@@ -85,6 +91,8 @@ def load():
         "ldpc_ctx_create": (C.c_int, [vp, i32, C.POINTER(vp)]),
         "ldpc_ctx_destroy": (None, [vp]),
         "ldpc_ctx_nms_kernel": (C.c_int, [vp]),
+        "ldpc_ctx_get_pb_tuning": (C.c_int, [vp, C.POINTER(PbTuning)]),
+        "ldpc_ctx_set_pb_tuning": (C.c_int, [vp, C.POINTER(PbTuning)]),
         # device entry points: device pointers travel as integers (tensor.data_ptr())
         "ldpc_nms_decode": (C.c_int, [vp, vp, i64, i32, C.POINTER(f32), f32, f32, vp, vp, vp, vp, i32, vp]),
         "ldpc_eval_counts": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),

@@ -232,6 +232,20 @@ __device__ __forceinline__ void pb_success_terms(const float *q, float2 *tq, int
     tq[lane] = make_float2(2.0f * (1.0f - qp), 2.0f * qp);
 }
 
+// the same from the table of q_p alone (the chunk kernels: half the LDS; the factor is formed per position, as pb_seq_kernel does)
+__device__ __forceinline__ bool pb_success_q(u64 D, float w1, const float *qpar, const PbFrame &F)
+{
+    const float ratio = (1.0f - w1) / w1;
+    float prod = 1.0f;
+#pragma unroll 8
+    for (int p = 0; p < 64; ++p) {
+        const float qp = qpar[p];
+        prod = prod * (((D >> p) & 1) ? 2.0f * qp : 2.0f * (1.0f - qp));
+    }
+    const float p_suc = 1.0f / (1.0f + ratio / prod);
+    return (double)p_suc > F.p_t_suc;
+}
+
 __device__ __forceinline__ bool pb_success(u64 D, float w1, const float2 *tq, const PbFrame &F)
 {
     const float ratio = (1.0f - w1) / w1;
@@ -517,22 +531,24 @@ struct PbSortArgs {
 };
 
 constexpr int kPbMaxTie = 16;
-constexpr int kPbWaveCap = 512;   // chunk capacity of the chunk kernel
+constexpr int kPbWaveCap = 384;   // chunk capacity of the chunk kernel (10 KiB of LDS per frame: four wavefronts per SIMD; 512 = 12 KiB = three)
 
 template <int CAP>
 struct __attribute__((aligned(16))) PbWaveLds {
     float pre[4];             // pre[3] = NaN: the "weight" under an exhausted cursor (0) -- its sum compares false with any bound
-    float w[128];             // |y'|                                         } words [4, 328): the image of the record
+    float w[128];             // |y'|                                         } words [4, 360): the image of the record
     u64 P[64];                // rows of P'                                   } pb_singles_kernel wrote for the frame
     float cdfA[68];           // P[Bin(64, p1) <= b] ROUNDED TO float32 -- the rules only ever read the table through a
                               // (float) cast (pb_not_promising), so storing the rounded value is the same arithmetic
+    unsigned char perm[128];  // original bit index of primed position p (for the codeword at the end)    } words [328, 360)
     float tail[4][17];        // tail[g][c] <= the sum of the c lightest parity weights of quarter g (pbw_cost_floor)
-    float2 tq[64];            // success-rule factors (pb_success_terms)
+    float qpar[64];           // q_p = sigmoid(c4 |y'_p|) of the parity positions (the success rule, pb_success_q)
     float cdfH[68];           // P[Bin(64, 1/2) <= b], float32 as cdfA
-    // the chunk: as walked (slots 0..n-1), then -- skewed, one pad entry per eight: lane-consecutive 64-bit accesses
-    // would otherwise fall on two LDS banks -- grouped by bucket and finally in visit order; 64 entries of slack take the
-    // overshoot of the walk's last trip and the "never before me" pad of the rank count
-    u64 keys[(CAP + 64) + (CAP + 64) / 8];
+    // the chunk: as walked (slots 0..n-1), then (sorted path only) grouped by bucket and finally in visit order; 64 entries of
+    // slack take the overshoot of the walk's last trip and the "never before me" pad of the rank count.  (Rounds 2-3 skewed
+    // the array by one pad entry per eight against the two-bank pattern of lane-consecutive 64-bit accesses in the sorted
+    // path, and let a trip overshoot by 128: 1.6 KiB that stood between the kernel and a fourth wavefront per SIMD.)
+    u64 keys[CAP + 64];
     union {
         int hist[CAP];        // bucket counts, then cursors; the costs of a chunk
         unsigned list[CAP + 64];   // the walk's work list (one entry per member emitted)
@@ -549,7 +565,7 @@ struct __attribute__((aligned(16))) PbWaveLds {
 };
 static_assert(sizeof(PbSortArgs) <= 384, "the sorted path's arguments borrow the candidate words");
 
-__device__ __forceinline__ int pbw_phys(int i) { return i + (i >> 3); }
+__device__ __forceinline__ int pbw_phys(int i) { return i; }
 
 // The weighted distance of a candidate, two ways.  The chunk kernel keeps no byte LUT (8 KiB of LDS per frame: with it two
 // wavefronts fit a SIMD, without it three to four, and the kernel spends half its time waiting):
@@ -688,7 +704,7 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int
 {
     unsigned long long plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
-    static_assert((CAP + 64) + (CAP + 64) / 8 >= CAP + 128, "a dense trip may write 127 keys past CAP");
+    static_assert(sizeof(L.keys) / 8 >= CAP + 64 && CAP >= 128, "a dense trip may write 63 keys past CAP");
     static_assert(offsetof(PbWaveLds<CAP>, w) >= 4 && offsetof(PbWaveLds<CAP>, w) == offsetof(PbWaveLds<CAP>, pre) + 16, "the NaN sits right in front of the weights");
     unsigned *const list = L.list;      // entry: q | owner lane << 5
     const float *const w = L.w;
@@ -771,7 +787,7 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int
         // keys inside a chunk is irrelevant, so the second members simply follow the first ones
         const int m = a - 1;
         const float s = sbv + w[m], s2 = sbv + w[m > 0 ? m - 1 : 0], s3 = sbv + w[m > 1 ? m - 2 : 0];
-        const bool two = has && m > base + 1 && s2 <= T;
+        const bool two = has && m > base + 1 && s2 <= T && cnt <= CAP - 64;      // (no second members in a trip that may end beyond CAP + 63)
         const int mlast = two ? m - 1 : m;
         const bool left = mlast > base + 1;                 // the item has members beyond this trip's
         const bool again = has && left && (two ? s3 : s2) <= T;
@@ -902,8 +918,8 @@ template <int CAP>
 __device__ __forceinline__ int pbw_scan_chunk(PbWaveLds<CAP> &L, const PbParams &P, const PbFrame &Fr, u64 d0, int n, float mn, float mx, int lane,
                                               PbwState &S, int &stop, int &ntep)
 {
-    constexpr int PER = CAP / 64;
-    static_assert(PER % 4 == 0, "the pass reads its keys four slices at a time");
+    constexpr int PER = CAP / 64, STEP = PER % 4 == 0 ? 4 : 3;
+    static_assert(CAP % 64 == 0 && PER % STEP == 0, "the pass reads its keys STEP slices at a time");
     if (S.nlive <= 1) return -1;      // (the first chunk: one entry in the frontier, its pops are counted one by one)
     const float best0 = S.best;
     // Rule 1 by probes.  With the best fixed, the rule's left-hand side bs = H[beta] + (A[beta] - H[beta]) w1 falls as the sum
@@ -933,11 +949,11 @@ __device__ __forceinline__ int pbw_scan_chunk(PbWaveLds<CAP> &L, const PbParams 
     // (branch-free first: the keys, their P' rows and the bound's table entries are read side by side for all of the lane's
     //  keys -- three LDS round trips per chunk instead of three per key)
 #pragma unroll
-    for (int k0 = 0; k0 < PER; k0 += 4) {      // (four keys at a time: eight side by side cost ~40 spilled registers of walk state)
+    for (int k0 = 0; k0 < PER; k0 += STEP) {      // (three or four keys at a time: all side by side cost registers)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = lane + 64 * (k0 + u); kq[k0 + u] = i < n ? L.keys[i] : ~0ull; }
+        for (int u = 0; u < STEP; ++u) { const int i = lane + 64 * (k0 + u); kq[k0 + u] = i < n ? L.keys[i] : ~0ull; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < STEP; ++u) {
             const int k = k0 + u, i = lane + 64 * k;
             const PbTep t = pbw_tep((unsigned)kq[k]);
             const float rs = __uint_as_float((unsigned)(kq[k] >> 32));      // (an empty slot: NaN, every test below is false)
@@ -1028,7 +1044,7 @@ __device__ __forceinline__ int pbw_scan_chunk(PbWaveLds<CAP> &L, const PbParams 
                 if (lane == 0) { L.rk[nrec] = key; L.rc[nrec] = c; }
                 ++nrec;
                 const float w1 = det_expf(P.c4 * __uint_as_float((unsigned)(key >> 32))) * Fr.spl;
-                if (pb_success(parity(pbw_tep((unsigned)key)), w1, L.tq, Fr)) stop2 = 1;
+                if (pb_success_q(parity(pbw_tep((unsigned)key)), w1, L.qpar, Fr)) stop2 = 1;
                 before = c;
             }
         }
@@ -1115,9 +1131,10 @@ __device__ __forceinline__ int pbw_process_chunk(PbWaveLds<CAP> &L, const PbPara
     // keys of its own bucket that sort before it.  Entries past a bucket's end belong to higher buckets (larger keys), past
     // the chunk's end to the all-ones pad: the count needs no mask and runs to the wave's fullest bucket.
     {
-        int4 *h4 = reinterpret_cast<int4 *>(&L.hist[lane * PER]);
+        static_assert(PER % 2 == 0, "a lane's bucket counters are read and written as pairs");
+        int2 *h2 = reinterpret_cast<int2 *>(&L.hist[lane * PER]);
 #pragma unroll
-        for (int k = 0; k < PER / 4; ++k) h4[k] = make_int4(0, 0, 0, 0);
+        for (int k = 0; k < PER / 2; ++k) h2[k] = make_int2(0, 0);
     }
     const float scale = mx > mn ? (float)CAP / (mx - mn) : 0.0f;
     const bool flat = !(scale < 3.0e38f);           // denormally close sums: one bucket
@@ -1141,18 +1158,18 @@ __device__ __forceinline__ int pbw_process_chunk(PbWaveLds<CAP> &L, const PbPara
     int maxsize;
     {
         int c[PER], local = 0, cmax = 0;
-        const int4 *h4 = reinterpret_cast<const int4 *>(&L.hist[lane * PER]);
+        const int2 *h2 = reinterpret_cast<const int2 *>(&L.hist[lane * PER]);
 #pragma unroll
-        for (int k = 0; k < PER / 4; ++k) { const int4 v = h4[k]; c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w; }
+        for (int k = 0; k < PER / 2; ++k) { const int2 v = h2[k]; c[2 * k] = v.x; c[2 * k + 1] = v.y; }
 #pragma unroll
         for (int k = 0; k < PER; ++k) { local += c[k]; cmax = c[k] > cmax ? c[k] : cmax; }
         int run = wave_incl_add_dpp(local) - local;
         maxsize = wave_max_i32(cmax);
 #pragma unroll
         for (int k = 0; k < PER; ++k) { const int t = c[k]; c[k] = run; run += t; }
-        int4 *o4 = reinterpret_cast<int4 *>(&L.hist[lane * PER]);
+        int2 *o2 = reinterpret_cast<int2 *>(&L.hist[lane * PER]);
 #pragma unroll
-        for (int k = 0; k < PER / 4; ++k) o4[k] = make_int4(c[4 * k], c[4 * k + 1], c[4 * k + 2], c[4 * k + 3]);
+        for (int k = 0; k < PER / 2; ++k) o2[k] = make_int2(c[2 * k], c[2 * k + 1]);
     }
     wave_fence();
 #pragma unroll
@@ -1290,7 +1307,7 @@ __device__ __forceinline__ int pbw_process_chunk(PbWaveLds<CAP> &L, const PbPara
                 if (c < before) {
                     const u64 D = parity(t);
                     before = c; lnb = i; ++nnb; lbest = c; lD = D; lcode = (unsigned)key;
-                    if (pb_success(D, w1, L.tq, Fr)) { lstop = i; lreason = 2; }
+                    if (pb_success_q(D, w1, L.qpar, Fr)) { lstop = i; lreason = 2; }
                 }
             }
         }
@@ -1371,10 +1388,9 @@ __device__ __forceinline__ int pbw_sorted_call(PbWaveLds<CAP> &L, const PbParams
 // A long search handed from the chunk kernel to the workgroup kernel: ONE record per frame with everything the search needs,
 // so that the receiving workgroup starts after a single wide load (its 1024 threads copy the record into LDS side by side)
 // instead of the chain frame number -> source index -> permutation -> y that the chunk kernel went through:
-//   words [0, 524)      the frame's tables as they stand in PbWaveLds (pad, w, P, cdfA, tail, tq), verbatim
-//   words [524, 1036)   the committed cursors, [8][64]
-//   words [1036, 1068)  the permutation, one byte per primed position (as in the singles record)
-//   words [1068, ...)   PbCarry: the search state (sums <= lo are visited) and the frame's scalars
+//   words [0, 492)      the frame's tables as they stand in PbWaveLds (pad, w, P, cdfA, perm, tail, q), verbatim
+//   words [492, 1004)   the committed cursors, [8][64]
+//   words [1004, ...)   PbCarry: the search state (sums <= lo are visited) and the frame's scalars
 struct PbCarry {
     float lo, best;
     int j, nlive, cmp, suc1, suc2, bestidx;
@@ -1384,15 +1400,23 @@ struct PbCarry {
     long long f;
     float tprev, nprev;      // the last chunk's lower bound and the TEPs before it (the growth exponent for the next bound)
 };
-constexpr int kPbRecPrefix = 524, kPbRecCur = 524, kPbRecPerm = 1036, kPbRecScalars = 1068, kPbRecWords = 1120;
+constexpr int kPbRecPrefix = 492, kPbRecCur = 492, kPbRecScalars = 1004, kPbRecWords = 1040;
+constexpr int kPbRecPerm = 328;       // (the permutation bytes inside the prefix: PbWaveLds::perm)
 static_assert(kPbRecScalars * 4 % 8 == 0 && kPbRecScalars * 4 + sizeof(PbCarry) <= kPbRecWords * 4, "record layout");
-static_assert(offsetof(PbWaveLds<kPbWaveCap>, cdfH) == kPbRecPrefix * 4, "the record's first part is the head of PbWaveLds");
+static_assert(offsetof(PbWaveLds<kPbWaveCap>, cdfH) == kPbRecPrefix * 4 && offsetof(PbWaveLds<kPbWaveCap>, perm) == kPbRecPerm * 4, "the record's first part is the head of PbWaveLds");
 
 // One frame of list A per wavefront, from its first TEP to its stop (or to the end of the table); massive ties go to
-// list B (list replay).  Workgroup b serves sub-list b mod 16, entries b / 16, b / 16 + grid / 16, ...
-// (12 KiB of LDS per frame: 13 workgroups per CU; three wavefronts per SIMD asked of the register allocator)
+// list B (list replay).  Workgroup b serves sub-list b mod 16, entries b / 16, b / 16 + grid / 16, ... -- with the grid the
+// launcher uses, ONE frame per workgroup: the hardware dispatcher then hands the next frame to whichever slot frees first.
+// (Measured and dropped in round 4: persistent workgroups that draw their frames by ticket and fetch the next frame's list entry
+//  and record while the current one is searched.  In-kernel stamps had put ~45 % of a wavefront's life into the dependent round
+//  trips list entry -> record at a frame's start and the permutation / result stores at its end, and with the prefetch those
+//  phases do vanish from the stamps -- but the launch got SLOWER: 359 -> 423 us at 2.5 dB, 5.03 -> 5.07 ms at 1.0 dB.  A frame
+//  bound early to a wavefront that is busy with a long search starts late, and the launch is its tail: 3.4 frames per
+//  resident wavefront at 2.5 dB; the other wavefronts of the SIMD had been hiding those round trips anyway.)
+// (12.1 KiB of LDS per frame: 13 workgroups per CU; three wavefronts per SIMD asked of the register allocator)
 template <int CAP, bool PROF, int ROT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb_wave_kernel(PbParams P,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb_wave_kernel(PbParams P,
                                                      const double *__restrict__ cdf_half, int *__restrict__ ctl,
                                                      const int *__restrict__ listA, int *__restrict__ listB, int sub_cap,
                                                      unsigned *__restrict__ carry,
@@ -1423,18 +1447,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
         // (a frame that starts late -- its workgroup waited for a slot -- would end the launch if it ran long here: it leaves sooner)
         const int budget = (len * kPbSub > P.late_min && len < P.late_maxlen && k * 100 >= len * P.late_pct) ? budget0 / P.late_div : budget0;
         const long long f = listA[sub * sub_cap + k];
-        // ---- per-frame set-up: ONE wide load of the record pb_singles_kernel wrote (P', |y'|, the CDF table: 324 words, copied
-        // into LDS as they are), the frame's scalars by scalar loads; derived here: the cost-bound table, the success-rule factors
+        // ---- per-frame set-up: ONE wide load of the record pb_singles_kernel wrote (|y'|, P', the CDF table, the permutation: 356
+        // words, copied into LDS as they are), the frame's scalars by scalar loads; derived here: the cost-bound table, the
+        // success-rule factors
         const unsigned *const rec = recs + f * kPbR1Words;
         {
             const uint4 *const r4 = reinterpret_cast<const uint4 *>(rec);
             uint4 *const l4 = reinterpret_cast<uint4 *>(L.w);
             const uint4 a = r4[lane];
             uint4 b = make_uint4(0, 0, 0, 0);
-            if (lane < 17) b = r4[64 + lane];
+            if (lane < 25) b = r4[64 + lane];
             if constexpr (PROF) { unsigned t = a.x; asm volatile("s_waitcnt vmcnt(0)" : "+v"(t)); PBW_STAMP(kPwLoad1); }
             l4[lane] = a;
-            if (lane < 17) l4[64 + lane] = b;
+            if (lane < 25) l4[64 + lane] = b;
         }
         const PbHead &H = *reinterpret_cast<const PbHead *>(rec + kPbR1Head);
         const PbFrame Fr = H.fr;
@@ -1450,8 +1475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
             for (int u = 0; u < 16; ++u) { const float o = L.w[64 + g0 + u]; r += (o < v) || (o == v && g0 + u < lane); }
             float *const srt = reinterpret_cast<float *>(L.keys);
             srt[g0 + r] = v;
-            const float qp = 1.0f / (1.0f + det_expf(-(P.c4 * v)));          // sigmoid(c4 |y'_p|), as pb_frame_setup computes it
-            L.tq[lane] = make_float2(2.0f * (1.0f - qp), 2.0f * qp);        // pb_success_terms
+            L.qpar[lane] = 1.0f / (1.0f + det_expf(-(P.c4 * v)));            // sigmoid(c4 |y'_p|), as pb_frame_setup computes it
             wave_fence();
             float acc = srt[lane];
             acc = acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x111, 0xF, 0xF, true));   // row_shr:1,2,4,8:
@@ -1516,7 +1540,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
                     for (int k = lane; k < kPbRecPrefix; k += 64) crec[k] = Lw[k];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) crec[kPbRecCur + k * 64 + lane] = W.ecur[k];
-                    if (lane < 32) crec[kPbRecPerm + lane] = rec[kPbR1Perm + lane];
                     if (lane == 0) {
                         PbCarry c;
                         c.lo = lo; c.best = S.best; c.j = S.j; c.nlive = S.nlive; c.cmp = S.cmp; c.suc1 = S.suc1; c.suc2 = S.suc2;
@@ -1528,17 +1551,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
                 }
             }
         }
-        if (state == 3) { wave_fence(); continue; }
         if (state == 2) {   // massive ties: the literal list replay decodes this frame
             if (lane == 0) listB[atomicAdd(&ctl[kPbCtlLenB], 1)] = (int)f;
-            wave_fence();
-            continue;
-        }
-        {   // candidate (E = flipped MRB positions, D = parity discrepancy) -> codeword in ORIGINAL bit order
+        } else if (state != 3) {   // candidate (E = flipped MRB positions, D = parity discrepancy) -> codeword in ORIGINAL bit order
             if (lane < 2) L.cw[lane] = 0;
             wave_fence();
-            const unsigned char *const pb = reinterpret_cast<const unsigned char *>(rec + kPbR1Perm);
-            const int o1 = pb[lane], o2 = pb[64 + lane];       // (original bit index of primed positions lane, 64 + lane)
+            const int o1 = L.perm[lane], o2 = L.perm[64 + lane];       // (original bit index of primed positions lane, 64 + lane)
             const u64 mrb_bits = H.hm ^ S.bestE, par_bits = S.bestD ^ H.hp;
             if ((mrb_bits >> lane) & 1) atomicOr(&L.cw[o1 >> 6], 1ull << (o1 & 63));
             if ((par_bits >> lane) & 1) atomicOr(&L.cw[o2 >> 6], 1ull << (o2 & 63));
@@ -1551,10 +1569,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pb
                 if (O.ntep) O.ntep[f] = ntep;
                 if (O.aux) { O.aux[f * 4] = S.cmp; O.aux[f * 4 + 1] = S.suc1; O.aux[f * 4 + 2] = S.suc2; O.aux[f * 4 + 3] = stop; }
             }
-            wave_fence();
+            PBW_STAMP(kPwStore);
+            if constexpr (PROF) pt[kPwFrames] += 1;
         }
-        PBW_STAMP(kPwStore);
-        if constexpr (PROF) pt[kPwFrames] += 1;
+        wave_fence();
     }
     if constexpr (PROF) { if (lane0 == 0 && pt[kPwFrames]) for (int k = 0; k < kPwSlots; ++k) atomicAdd(&prof_out[k], pt[k]); }
 }
@@ -1986,7 +2004,7 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
                     if (lane == 0) { L.rk[nrec] = key; L.rc[nrec] = c; }
                     ++nrec;
                     const float w1 = det_expf(P.c4 * __uint_as_float((unsigned)(key >> 32))) * Fr.spl;
-                    if (pb_success(parity(pbw_tep((unsigned)key)), w1, T0.tq, Fr)) stop2 = 1;
+                    if (pb_success_q(parity(pbw_tep((unsigned)key)), w1, T0.qpar, Fr)) stop2 = 1;
                     before = c;
                 }
             }
@@ -2456,8 +2474,20 @@ __global__ __launch_bounds__(64) void pb_ctl_clear_kernel(int *__restrict__ ctl)
     for (int i = threadIdx.x; i < kPbCtlInts; i += 64) ctl[i] = 0;
 }
 
-int pb_ctx_init(ldpc_ctx *)
+// chunk targets: the first chunk's count is only guessed (+-40 %), the others follow the growth of the counts
+ldpc_pb_tuning pb_default_tuning()
 {
+    ldpc_pb_tuning t;
+    t.budget = 4096; t.budget_s = t.budget / 8; t.budget_m = t.budget / 4; t.budget_l = 2 * t.budget; t.budget_xl = 6 * t.budget;
+    t.t1 = 320; t.t2 = kPbWaveCap * 13 / 16; t.t3 = 3072;
+    t.late_min = 4608; t.late_maxlen = 4400; t.late_pct = 1000; t.late_div = 4;
+    t.handoff_maxlen = 1 << 30;
+    return t;
+}
+
+int pb_ctx_init(ldpc_ctx *ctx)
+{
+    state(ctx)->pb_tuning = pb_default_tuning();
     static_assert(sizeof(PbCoopLds<kPbCoopW>) <= 160 * 1024, "one workgroup per CU");
     LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_coop_kernel<kPbCoopW, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(PbCoopLds<kPbCoopW>)));
@@ -2537,35 +2567,27 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     if ((rc = stream_ws_pb(ctx, s, F, stride, &w))) return rc;
     PbParams pp;
     pp.order = p->order; pp.nmax = (int)nmax; pp.cmin_off = spill_slots;
-    pp.t3 = 3072; pp.budget = 4096;
-    pp.t1 = 320; pp.t2 = kPbWaveCap * 13 / 16;
     // When a search leaves the chunk kernel for the workgroup kernel: after `budget` TEPs, the budget chosen ON THE DEVICE from the
     // length of the frame's sub-list of list A (a sixteenth of the frames that search beyond the weight-1 head), so that the
     // workgroup kernel gets the tails, 1000-3500 frames a call, and never the bulk (its list holds kPbHeavyCap frames).
-    // Measured per 131 072-frame step, PB kernels with the budget of the schedule / the neighbouring ones / no hand-over:
+    // Measured per 131 072-frame step (round 3), PB kernels with the budget of the schedule / the neighbouring ones / no hand-over:
     //   3.5 dB (length 42)    512: 0.20 ms              2.0 dB  (1750)   8192: 1.50 | 4096: 1.52 | 16384: 1.61 | none 1.80
     //   3.0 dB (177)         1024: 0.34                 1.75 dB (2560)   8192: 2.20 | 16384: 2.26 | 4096: 2.91 | none 2.50
     //   2.5 dB (626)         4096: 0.70 | 2048: 0.70    1.5 dB  (3475)  16384: 3.22 | 8192: 3.78 | none 3.41
     //   2.25 dB (1090)       4096: 1.02 | none 1.45     1.0 dB  (5300)  16384: 6.26 | 8192: 6.85 | none 6.44
     // (serial kernel sums; with four batches in flight -- bench.py's graph -- 24576 beats 16384 and none at 1.0 dB: 2.15 / 2.12 / 2.14 x 10^7
     //  frames/s, and ties with 16384 at 1.5 dB: 4.25 x 10^7 against 4.18 without)
-    pp.handoff_maxlen = 1 << 30;
-    if (const char *e = getenv("LDPC_PB_HANDOFF_MAXLEN")) pp.handoff_maxlen = atoi(e);
-    pp.budget_s = pp.budget / 8; pp.budget_m = pp.budget / 4;
-    if (const char *e = getenv("LDPC_PB_BUDGET")) pp.budget = atoi(e);   // (tuning aids)
-    if (const char *e = getenv("LDPC_PB_BUDGET_S")) pp.budget_s = atoi(e);
-    if (const char *e = getenv("LDPC_PB_BUDGET_M")) pp.budget_m = atoi(e);
-    pp.budget_l = 2 * pp.budget; pp.budget_xl = 6 * pp.budget;
-    if (const char *e = getenv("LDPC_PB_BUDGET_L")) pp.budget_l = atoi(e);
-    if (const char *e = getenv("LDPC_PB_BUDGET_XL")) pp.budget_xl = atoi(e);
-    if (const char *e = getenv("LDPC_PB_T3")) pp.t3 = atoi(e);
-    pp.late_min = 4608; pp.late_maxlen = 4400; pp.late_pct = 1000; pp.late_div = 4;
-    if (const char *e = getenv("LDPC_PB_LATE_PCT")) pp.late_pct = atoi(e);
-    if (const char *e = getenv("LDPC_PB_LATE_DIV")) pp.late_div = atoi(e);
-    if (const char *e = getenv("LDPC_PB_LATE_MIN")) pp.late_min = atoi(e);
-    if (const char *e = getenv("LDPC_PB_T2")) pp.t2 = atoi(e);
-    if (const char *e = getenv("LDPC_PB_T1")) pp.t1 = atoi(e);
-   // chunk targets: the first chunk's count is only guessed (+-40 %), the others follow the growth of the counts
+    // The schedule is a property of the CONTEXT (ldpc_ctx_set_pb_tuning, validated there; defaults: pb_default_tuning) and is
+    // copied here under the state's lock: no environment variable is read on the decode path (rounds 1-3 read thirteen).
+    ldpc_pb_tuning tn;
+    {
+        std::lock_guard<std::mutex> lock(st->mu);
+        tn = st->pb_tuning;
+    }
+    pp.budget = tn.budget; pp.budget_s = tn.budget_s; pp.budget_m = tn.budget_m; pp.budget_l = tn.budget_l; pp.budget_xl = tn.budget_xl;
+    pp.t1 = tn.t1; pp.t2 = tn.t2; pp.t3 = tn.t3;
+    pp.late_min = tn.late_min; pp.late_maxlen = tn.late_maxlen; pp.late_pct = tn.late_pct; pp.late_div = tn.late_div;
+    pp.handoff_maxlen = tn.handoff_maxlen;
     pp.c4 = (float)(-4.0 * (1.0 / pow(10.0, (double)p->snr_db / 10.0)));    // -4 * noise_variance, pb_testing.py:50-52
     const int mode = (p->reserved & 4) ? 2 : ((p->reserved & 2) ? 1 : 0);
     PbOut O{reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep, reinterpret_cast<int *>(p->d_aux)};
@@ -2608,6 +2630,8 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
         else hipLaunchKernelGGL((pb_wave_kernel<kPbWaveCap, PROFILED, 0>), dim3(g2), dim3(64), 0, s, pp, st->d_cdf_half, w->d_pb_ctl, \
                                 listA, listB, sub_cap, carry, recs, O, prof_ptr);                                                    \
     } while (0)
+    // chunk kernel: one workgroup (= one wavefront) per (sub-list, entry); a multiple of 16 workgroups, at most 65 536 (a
+    // workgroup then takes every 4096th entry of its sub-list).  Workgroups beyond their sub-list's length leave at once.
     const int64_t g2w = ((F + kPbSub - 1) / kPbSub) * kPbSub;
     const unsigned g2 = (unsigned)(g2w < 65536 ? g2w : 65536);
     if (!profile_s) {
@@ -2653,3 +2677,36 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
 }
 
 }  // namespace ldpc
+
+extern "C" {
+
+int ldpc_ctx_get_pb_tuning(ldpc_ctx *ctx, ldpc_pb_tuning *out)
+{
+    using namespace ldpc;
+    if (!ctx || !out || !ctx->osd_state) return fail(LDPC_E_ARG, "ldpc_ctx_get_pb_tuning: null argument");
+    OsdState *st = state(ctx);
+    std::lock_guard<std::mutex> lock(st->mu);
+    *out = st->pb_tuning;
+    return LDPC_OK;
+}
+
+int ldpc_ctx_set_pb_tuning(ldpc_ctx *ctx, const ldpc_pb_tuning *t)
+{
+    using namespace ldpc;
+    if (!ctx || !ctx->osd_state) return fail(LDPC_E_ARG, "ldpc_ctx_set_pb_tuning: null context");
+    ldpc_pb_tuning v = t ? *t : pb_default_tuning();
+    const int budgets[5] = {v.budget_s, v.budget_m, v.budget, v.budget_l, v.budget_xl};
+    for (int b : budgets)
+        if (b < 1) return fail(LDPC_E_ARG, "ldpc_ctx_set_pb_tuning: hand-over budgets must be >= 1 TEP (got %d)", b);
+    if (v.t1 < 32 || v.t1 > kPbWaveCap || v.t2 < 32 || v.t2 > kPbWaveCap)
+        return fail(LDPC_E_ARG, "ldpc_ctx_set_pb_tuning: chunk targets t1 / t2 must lie in [32, %d] (got %d, %d)", kPbWaveCap, v.t1, v.t2);
+    if (v.t3 < 256 || v.t3 > kCoopCap) return fail(LDPC_E_ARG, "ldpc_ctx_set_pb_tuning: t3 must lie in [256, %d] (got %d)", kCoopCap, v.t3);
+    if (v.late_div < 1 || v.late_pct < 0 || v.late_min < 0 || v.late_maxlen < 0 || v.handoff_maxlen < 0)
+        return fail(LDPC_E_ARG, "ldpc_ctx_set_pb_tuning: late_div must be >= 1 and the other fields >= 0");
+    OsdState *st = state(ctx);
+    std::lock_guard<std::mutex> lock(st->mu);
+    st->pb_tuning = v;
+    return LDPC_OK;
+}
+
+}  // extern "C"

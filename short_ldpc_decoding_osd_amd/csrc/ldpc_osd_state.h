@@ -43,7 +43,8 @@ struct OsdState {
     double *d_cdf_half = nullptr;     // PB-OSD: P[Bin(64, 1/2) <= b], b = 0..64
     unsigned long long *d_index_errors = nullptr;   // ldpc_osd_params.y_frames: out-of-range entries met so far
     int fs_off[4] = {0, 0, 0, 0}, fs_cnt[4] = {0, 0, 0, 0};
-    std::mutex mu;                    // guards `ws` and `reserve_frames`
+    ldpc_pb_tuning pb_tuning;         // PB-OSD hand-over schedule and chunk targets (ldpc_ctx_set_pb_tuning); read under `mu`
+    std::mutex mu;                    // guards `ws`, `reserve_frames` and `pb_tuning`
     std::unordered_map<hipStream_t, StreamWs> ws;
     int64_t reserve_frames = 0;       // ldpc_osd_reserve: smallest capacity any workspace is created with
 };

@@ -146,6 +146,26 @@ class Decoder:
         st = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
         _lib.check(self.L.ldpc_osd_release_stream(self._ctx, st), "ldpc_osd_release_stream")
 
+    def pb_tuning(self):
+        """The context's PB-OSD tuning (hand-over budgets, chunk targets) as a dict; see include/ldpc_osd.h."""
+        t = _lib.PbTuning()
+        _lib.check(self.L.ldpc_ctx_get_pb_tuning(self._ctx, C.byref(t)), "ldpc_ctx_get_pb_tuning")
+        return {n: int(getattr(t, n)) for n, _ in _lib.PbTuning._fields_}
+
+    def set_pb_tuning(self, **fields):
+        """Change PB-OSD tuning fields of the context (no field: back to the defaults).  Results do not depend on them;
+        applies to calls issued afterwards.  Returns the previous setting (a dict that can be passed back)."""
+        prev = self.pb_tuning()
+        if not fields:
+            _lib.check(self.L.ldpc_ctx_set_pb_tuning(self._ctx, None), "ldpc_ctx_set_pb_tuning")
+            return prev
+        unknown = set(fields) - set(prev)
+        if unknown:
+            raise ValueError(f"unknown PB-OSD tuning field(s): {sorted(unknown)}")
+        t = _lib.PbTuning(**{**prev, **{k: int(v) for k, v in fields.items()}})
+        _lib.check(self.L.ldpc_ctx_set_pb_tuning(self._ctx, C.byref(t)), "ldpc_ctx_set_pb_tuning")
+        return prev
+
     def osd_index_errors(self):
         """Out-of-range frame-list entries met by calls that carried ``y_frames`` (synchronises the device)."""
         n = C.c_int64(0)

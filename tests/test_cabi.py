@@ -18,10 +18,16 @@ def test_header_and_binding_agree():
     L = _lib.load()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.ldpc_abi_version() == int(re.search(r"#define LDPC_OSD_ABI_VERSION (\d+)", hdr).group(1)) == 3
+    assert L.ldpc_abi_version() == int(re.search(r"#define LDPC_OSD_ABI_VERSION (\d+)", hdr).group(1)) == 4
     # struct layouts the binding mirrors (a silent drift here corrupts every OSD call)
     import ctypes as C
     assert C.sizeof(_lib.OsdParams) == 48 and _lib.OsdParams.d_aux.offset == 32 and _lib.OsdParams.y_frames.offset == 40
+    # ldpc_pb_tuning: thirteen int32 in the header's order (ABI 4)
+    m = re.search(r"typedef struct ldpc_pb_tuning \{(.*?)\} ldpc_pb_tuning;", hdr, re.S)
+    names = [n.strip() for decl in re.findall(r"int32_t ([^;]+);", m.group(1)) for n in decl.split(",")]
+    assert names == [n for n, _ in _lib.PbTuning._fields_] and C.sizeof(_lib.PbTuning) == 4 * len(names) == 52
+    assert _lib.PbTuning.t1.offset == 20 and _lib.PbTuning.handoff_maxlen.offset == 48
+    assert "getenv" not in re.sub(r'getenv\("LDPC_PB_PROFILE"\)', "", open(os.path.join(ROOT, "short_ldpc_decoding_osd_amd", "csrc", "ldpc_osd_pb.hip")).read())
 
 
 @pytest.mark.parametrize("name,alist", [

@@ -52,7 +52,7 @@ def _check(dec, y, cw, order, snr, path, ref=None):
 PATHS = [None, "block", "replay"]
 
 
-@pytest.mark.parametrize("snr,order,frames", [(2.5, 2, 3000), (2.5, 3, 1500), (1.0, 2, 600), (3.5, 3, 6000), (2.5, 1, 800)])
+@pytest.mark.parametrize("snr,order,frames", [(2.5, 2, 3000), (2.5, 3, 1500), (1.0, 2, 600), (3.5, 3, 6000), (2.5, 1, 800), (2.0, 3, 900), (3.0, 3, 3000)])
 def test_pb_matches_oracle(dec, snr, order, frames):
     y, cw = _failures(dec, snr, frames, seed=int(snr * 10) + order)
     y, cw = y[:600], cw[:600]
@@ -115,35 +115,59 @@ def test_pb_other_input_scalings(dec, scale):
     _check(dec, y, cw, 3, snr, "block", ref)
 
 
-def test_pb_workgroup_kernel_overflowing_hand_over(dec, monkeypatch):
-    """The workgroup kernel takes at most 4096 searches a call: with the hand-over budget forced to 64 TEPs (tuning
-    variables of launch_pb) more than that ask to leave the chunk kernel -- the first 4096 are finished by the workgroup
+def test_pb_workgroup_kernel_overflowing_hand_over(dec):
+    """The workgroup kernel takes at most 4096 searches a call: with the hand-over budget forced to 64 TEPs (the context's
+    tuning, ldpc_ctx_set_pb_tuning) more than that ask to leave the chunk kernel -- the first 4096 are finished by the workgroup
     kernel from their first chunks on, the others stay where they are.  Same counts, stops, winners and metrics."""
-    for v in ("LDPC_PB_BUDGET_S", "LDPC_PB_BUDGET_M", "LDPC_PB_BUDGET", "LDPC_PB_BUDGET_L", "LDPC_PB_BUDGET_XL"):
-        monkeypatch.setenv(v, "64")
-    y, cw = _failures(dec, 1.5, 14000, seed=5)
-    y, cw = y[:8000], cw[:8000]
-    assert y.shape[0] == 8000
-    ref = _check(dec, y, cw, 3, 1.5, None)
-    assert (ref["num_teps"] > 64).sum() > 4096 + 200
+    prev = dec.set_pb_tuning(budget_s=64, budget_m=64, budget=64, budget_l=64, budget_xl=64)
+    try:
+        assert dec.pb_tuning()["budget_xl"] == 64
+        y, cw = _failures(dec, 1.5, 14000, seed=5)
+        y, cw = y[:8000], cw[:8000]
+        assert y.shape[0] == 8000
+        ref = _check(dec, y, cw, 3, 1.5, None)
+        assert (ref["num_teps"] > 64).sum() > 4096 + 200
+    finally:
+        dec.set_pb_tuning(**prev)
+    assert dec.pb_tuning() == prev
+
+
+def test_pb_tuning_is_validated(dec):
+    """Bad values are refused and change nothing (LDPC_PB_LATE_DIV=0 used to reach the kernel); no field = defaults."""
+    from short_ldpc_decoding_osd_amd import _lib
+    before = dec.pb_tuning()
+    for bad in (dict(late_div=0), dict(budget=0), dict(t2=513), dict(t1=8), dict(t3=5000), dict(budget_xl=-1)):
+        with pytest.raises(_lib.LdpcError):
+            dec.set_pb_tuning(**bad)
+        assert dec.pb_tuning() == before
+    with pytest.raises(ValueError):
+        dec.set_pb_tuning(no_such_field=1)
+    dec.set_pb_tuning(t2=256, late_pct=65, late_div=2)
+    assert dec.pb_tuning()["t2"] == 256
+    dec.set_pb_tuning()
+    assert dec.pb_tuning() == before == dict(budget=4096, budget_s=512, budget_m=1024, budget_l=8192, budget_xl=24576, t1=320, t2=312,
+                                             t3=3072, late_min=4608, late_maxlen=4400, late_pct=1000, late_div=4, handoff_maxlen=1 << 30)
 
 
 @pytest.mark.parametrize("quant", [1024.0, 16384.0])
-def test_pb_workgroup_kernel_ties(dec, quant, monkeypatch):
+def test_pb_workgroup_kernel_ties(dec, quant):
     """Long searches on finely quantised channel values: equal sums deep inside a search, where the workgroup kernel's
     sort-free pass meets a tie against a reference key and wavefront 0 redoes the chunk with the sorted path."""
-    monkeypatch.setenv("LDPC_PB_BUDGET_S", "128")
-    rng = np.random.default_rng(int(quant) + 1)
-    y, cw = np_oracle.make_frames(dec.code.G, 1.0, 400, rng)
-    y = (np.round(y * quant) / quant).astype(np.float32)
-    soft = c_oracle.nms(dec.code.H, y, 10, ALPHA0)
-    _, fail, _ = c_oracle.evaluate(dec.code.H, soft, cw)
-    idx = np.flatnonzero(fail)[:96]
-    ref = _check(dec, y[idx], cw[idx], 3, 1.0, None)
-    assert ref["num_teps"].max() > 8000
+    prev = dec.set_pb_tuning(budget_s=128)
+    try:
+        rng = np.random.default_rng(int(quant) + 1)
+        y, cw = np_oracle.make_frames(dec.code.G, 1.0, 400, rng)
+        y = (np.round(y * quant) / quant).astype(np.float32)
+        soft = c_oracle.nms(dec.code.H, y, 10, ALPHA0)
+        _, fail, _ = c_oracle.evaluate(dec.code.H, soft, cw)
+        idx = np.flatnonzero(fail)[:96]
+        ref = _check(dec, y[idx], cw[idx], 3, 1.0, None)
+        assert ref["num_teps"].max() > 8000
+    finally:
+        dec.set_pb_tuning(**prev)
 
 
-@pytest.mark.parametrize("snr,B", [(2.5, 131072), (1.0, 65536)])
+@pytest.mark.parametrize("snr,B", [(2.5, 131072), (1.0, 131072)])
 def test_pb_full_size_properties(dec, snr, B):
     """BASELINE config 5 sizes: size-independent properties of PB-OSD order 3 on the NMS failures of a full batch.
     The chunk bounds, the hand-over to the workgroup kernel and the order of the keys inside a chunk depend on the batch
