@@ -324,10 +324,11 @@ struct PbOut {
 // needs, so that the receiving wavefront starts after a single wide load instead of the chain frame number -> source
 // index -> permutation -> y (round 3; the record replaces the separate 1096-byte PbPrep table of rounds 2-3):
 //   words [0, 128)     w[128]     |y'|                                       } the head of PbWaveLds (behind its four pad
-//   words [128, 256)   P[64]      rows of P'                                 } words): the chunk kernel copies these 324 words
-//   words [256, 324)   cdfA[68]   P[Bin(64, p1) <= b] rounded to float32     } into LDS as they are
-//   words [324, 356)   perm[128]  original bit index of primed position p, one byte each
-//   words [356, ...)   PbHead     the frame's scalars and the search state after the weight-1 head
+//   words [128, 256)   P[64]      rows of P'                                 } words): the chunk kernel copies these 360 words
+//   words [256, 258)   0          the "row" an unused position of a key reads } into LDS as they are
+//   words [258, 326)   cdfA[68]   P[Bin(64, p1) <= b] rounded to float32     }
+//   words [326, 358)   perm[128]  original bit index of primed position p, one byte each (+ 2 pad words)
+//   words [360, ...)   PbHead     the frame's scalars and the search state after the weight-1 head
 // Derived on arrival (a few dozen instructions): the cost-bound table (sorted parity weights) and the success-rule factors.
 struct PbHead {
     PbFrame fr;
@@ -336,7 +337,7 @@ struct PbHead {
     float hbest;
     int nhead, hsuc2, hbestidx;
 };
-constexpr int kPbR1Perm = 324, kPbR1Head = 356, kPbR1Words = 384;
+constexpr int kPbR1Zero = 256, kPbR1Cdf = 258, kPbR1Perm = 326, kPbR1Copy = 360, kPbR1Head = 360, kPbR1Words = 384;
 static_assert(kPbR1Head * 4 % 8 == 0 && kPbR1Head * 4 + sizeof(PbHead) <= kPbR1Words * 4, "record layout");
 
 template <class LDS>
@@ -438,8 +439,9 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
             unsigned *const R = recs + f * kPbR1Words;
             R[lane] = __float_as_uint(L.w[lane]); R[64 + lane] = __float_as_uint(L.w[64 + lane]);
             reinterpret_cast<u64 *>(R + 128)[lane] = L.P[lane];
-            R[256 + lane] = __float_as_uint((float)W.cdfA[lane]);
-            if (lane < 4) R[320 + lane] = lane == 0 ? __float_as_uint((float)W.cdfA[64]) : 0u;
+            if (lane < 2) R[kPbR1Zero + lane] = 0u;
+            R[kPbR1Cdf + lane] = __float_as_uint((float)W.cdfA[lane]);
+            if (lane < 4) R[kPbR1Cdf + 64 + lane] = lane == 0 ? __float_as_uint((float)W.cdfA[64]) : 0u;
             if (lane < 32) R[kPbR1Perm + lane] = reinterpret_cast<const unsigned *>(L.perm)[lane];
             {   // the head's result: nhead TEPs popped and evaluated, the last improvement among them (if any)
                 const u64 nbm = __ballot(newbest);
@@ -536,11 +538,13 @@ constexpr int kPbWaveCap = 384;   // chunk capacity of the chunk kernel (10 KiB 
 template <int CAP>
 struct __attribute__((aligned(16))) PbWaveLds {
     float pre[4];             // pre[3] = NaN: the "weight" under an exhausted cursor (0) -- its sum compares false with any bound
-    float w[128];             // |y'|                                         } words [4, 360): the image of the record
+    float w[128];             // |y'|                                         } words [4, 364): the image of the record
     u64 P[64];                // rows of P'                                   } pb_singles_kernel wrote for the frame
+    u64 Pzero;                // = 0: "row 64", what the unused positions of a pair's or a single's key read (no select)
     float cdfA[68];           // P[Bin(64, p1) <= b] ROUNDED TO float32 -- the rules only ever read the table through a
                               // (float) cast (pb_not_promising), so storing the rounded value is the same arithmetic
-    unsigned char perm[128];  // original bit index of primed position p (for the codeword at the end)    } words [328, 360)
+    unsigned char perm[128];  // original bit index of primed position p (for the codeword at the end)
+    unsigned rpad[2];         // (the record's image ends here: 360 words)
     float tail[4][17];        // tail[g][c] <= the sum of the c lightest parity weights of quarter g (pbw_cost_floor)
     float qpar[64];           // q_p = sigmoid(c4 |y'_p|) of the parity positions (the success rule, pb_success_q)
     float cdfH[68];           // P[Bin(64, 1/2) <= b], float32 as cdfA
@@ -610,11 +614,14 @@ __device__ __forceinline__ float pbw_cost(const PbWaveLds<CAP> &L, float mrb, u6
     return c;
 }
 
-// positions of a key's low word: p0 | p1 << 8 | p2 << 16 | weight << 24 (ascending positions, unused = 0)
+// positions of a key's low word: p0 | p1 << 8 | p2 << 16 | weight << 24 (ascending positions; an unused position is 64, the
+// zero row behind P').  Keys made by the chunk kernel's walk carry, in bits 26-27, the frontier growth of the TEP's pop plus
+// one (pb_delta + 1 = 0, 1, 2: the walk knows it from the item's geometry; unpacked from the positions it is ~25 instructions)
 __device__ __forceinline__ PbTep pbw_tep(unsigned code)
 {
-    return PbTep{(int)(code & 255u), (int)((code >> 8) & 255u), (int)((code >> 16) & 255u), (int)(code >> 24)};
+    return PbTep{(int)(code & 255u), (int)((code >> 8) & 255u), (int)((code >> 16) & 255u), (int)((code >> 24) & 3u)};
 }
+constexpr unsigned kPbUnused1 = 64u << 8, kPbUnused2 = 64u << 16;
 
 // the items of a lane (see above).  base: the members are m in (base, 63]; code / sh: a member's key is code | m << sh
 struct PbwItem {
@@ -628,7 +635,7 @@ __device__ __forceinline__ PbwItem pbw_item_rt(int q, int l)
     it.i = tri ? (first ? l : l - 62 + q) : l;
     it.j = tri ? (first ? l + 1 + q : l) : l;
     it.base = tri ? (l <= 62 ? it.j : 63) : (l <= 62 ? l : -1);
-    it.code = tri ? ((3u << 24) | ((unsigned)it.j << 8) | (unsigned)it.i) : (l <= 62 ? ((2u << 24) | (unsigned)l) : (1u << 24));
+    it.code = tri ? ((3u << 24) | ((unsigned)it.j << 8) | (unsigned)it.i) : (l <= 62 ? ((2u << 24) | kPbUnused2 | (unsigned)l) : ((1u << 24) | kPbUnused2 | kPbUnused1));
     it.sh = tri ? 16 : (l <= 62 ? 8 : 0);
     return it;
 }
@@ -778,8 +785,9 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int
             code = (3u << 24) | ((unsigned)j << 8) | (unsigned)i;
         } else {
             i = l; j = l; base = l <= 62 ? l : -1; sh = l <= 62 ? 8 : 0;
-            code = l <= 62 ? ((2u << 24) | (unsigned)l) : (1u << 24);
+            code = l <= 62 ? ((2u << 24) | kPbUnused2 | (unsigned)l) : ((1u << 24) | kPbUnused2 | kPbUnused1);
         }
+        const int wt = q < 31 ? 3 : (l <= 62 ? 2 : 1);
         unsigned char *const cb = reinterpret_cast<unsigned char *>(&L.cur[q >> 2][l]) + (q & 3);
         const int a = has ? (int)*cb : 1;
         const float sbv = q < 31 ? w[i] + w[j] : (l <= 62 ? w[l] : 0.0f);
@@ -798,8 +806,13 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int
         const int nt = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(more >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)more, 0u));
         wave_fence();                    // (every lane has read its entry: the slots may be written now)
         if (has) {
-            L.keys[pos] = ((u64)__float_as_uint(s) << 32) | (code | ((unsigned)m << sh));
-            if (two) L.keys[pos2] = ((u64)__float_as_uint(s2) << 32) | (code | ((unsigned)(m - 1) << sh));
+            const unsigned tmpl = code;       // (the field of the LAST position is zero in it; unused fields hold 64)
+            // frontier growth of the pop (pb_delta): the extended child exists below position 63 and below the order, the
+            // adjacent child if the last position can move down by one; + 1, in bits 26-27
+            const unsigned g1 = (unsigned)((m < 63 && wt < order) + (m > base + 1)) << 26;
+            const unsigned g2 = (unsigned)((wt < order) + (m - 1 > base + 1)) << 26;
+            L.keys[pos] = ((u64)__float_as_uint(s) << 32) | (tmpl | g1 | ((unsigned)m << sh));
+            if (two) L.keys[pos2] = ((u64)__float_as_uint(s2) << 32) | (tmpl | g2 | ((unsigned)(m - 1) << sh));
             *cb = (unsigned char)(left ? mlast : 0);        // (0: exhausted -- the list pass then reads the NaN)
             if (again) list[nt] = ent;
         }
@@ -944,27 +957,52 @@ __device__ __forceinline__ int pbw_scan_chunk(PbWaveLds<CAP> &L, const PbParams 
     };
     u64 kq[PER];
     unsigned npneed = 0, npmask = 0, survmask = 0;
-    int sumdel = 0, neg = 0, nsurv = 0;
+    int sumf = 0, neg = 0, nsurv = 0;
     unsigned short *const slist = reinterpret_cast<unsigned short *>(L.list);     // keys the cost bound could not rule out
-    // (branch-free first: the keys, their P' rows and the bound's table entries are read side by side for all of the lane's
-    //  keys -- three LDS round trips per chunk instead of three per key)
+    // Branch-free, STEP keys of the lane side by side: the keys, then their three P' rows each (an unused position reads the
+    // zero row: no select), then the bound's four table entries each -- three LDS round trips per STEP keys.  An empty slot
+    // holds a key whose sum is a NaN (every comparison false), whose positions read in-range garbage and whose growth field
+    // says 0: no validity mask anywhere.  (Round 3's form compiled to a branch and a wait behind every single LDS read.)
+    constexpr u64 kEmpty = 0xFFFFFFFFF7FFFFFFull;
+    const char *const Pb = reinterpret_cast<const char *>(L.P);
+    const char *const tb = reinterpret_cast<const char *>(L.tail);
+    const unsigned d0l = (unsigned)d0, d0h = (unsigned)(d0 >> 32);
 #pragma unroll
-    for (int k0 = 0; k0 < PER; k0 += STEP) {      // (three or four keys at a time: all side by side cost registers)
+    for (int k0 = 0; k0 < PER; k0 += STEP) {
 #pragma unroll
-        for (int u = 0; u < STEP; ++u) { const int i = lane + 64 * (k0 + u); kq[k0 + u] = i < n ? L.keys[i] : ~0ull; }
+        for (int u = 0; u < STEP; ++u) { const int i = lane + 64 * (k0 + u); kq[k0 + u] = i < n ? L.keys[i] : kEmpty; }
+        uint2 r0[STEP], r1[STEP], r2[STEP];
 #pragma unroll
         for (int u = 0; u < STEP; ++u) {
-            const int k = k0 + u, i = lane + 64 * k;
-            const PbTep t = pbw_tep((unsigned)kq[k]);
-            const float rs = __uint_as_float((unsigned)(kq[k] >> 32));      // (an empty slot: NaN, every test below is false)
-            const bool surv = i < n && pbw_cost_floor<CAP>(L, rs, parity(t)) < best0;
+            const unsigned code = (unsigned)kq[k0 + u];
+            r0[u] = *reinterpret_cast<const uint2 *>(Pb + ((code & 255u) << 3));
+            r1[u] = *reinterpret_cast<const uint2 *>(Pb + (((code >> 8) & 255u) << 3));
+            r2[u] = *reinterpret_cast<const uint2 *>(Pb + (((code >> 16) & 255u) << 3));
+        }
+        float t0[STEP], t1[STEP], t2[STEP], t3[STEP];
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) {
+            const unsigned lo = __builtin_amdgcn_bitop3_b32(r0[u].x, r1[u].x, r2[u].x, 0x96) ^ d0l;
+            const unsigned hi = __builtin_amdgcn_bitop3_b32(r0[u].y, r1[u].y, r2[u].y, 0x96) ^ d0h;
+            t0[u] = *reinterpret_cast<const float *>(tb + (__popc(lo & 0xFFFFu) << 2));
+            t1[u] = *reinterpret_cast<const float *>(tb + 68 + (__popc(lo >> 16) << 2));
+            t2[u] = *reinterpret_cast<const float *>(tb + 136 + (__popc(hi & 0xFFFFu) << 2));
+            t3[u] = *reinterpret_cast<const float *>(tb + 204 + (__popc(hi >> 16) << 2));
+        }
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) {
+            const int k = k0 + u;
+            const unsigned code = (unsigned)kq[k];
+            const float rs = __uint_as_float((unsigned)(kq[k] >> 32));
+            const bool surv = (((rs + t0[u]) + t1[u]) + (t2[u] + t3[u])) * 0.99999f < best0;      // (pbw_cost_floor)
             survmask |= surv ? 1u << k : 0u;
             npneed |= rs > r_safe ? 1u << k : 0u;
-            const int dl = i < n ? pb_delta(t, P.order) : 0;
-            sumdel += dl; neg += dl < 0;
+            const int fld = (int)((code >> 26) & 3u);     // growth + 1
+            sumf += fld; neg += fld == 0;
         }
-        asm volatile("" : "+v"(survmask), "+v"(npneed), "+v"(sumdel), "+v"(neg) : : "memory");
+        asm volatile("" : "+v"(survmask), "+v"(npneed), "+v"(sumf), "+v"(neg) : : "memory");
     }
+    const int sumdel = sumf - PER;       // (every slot, empty or not, carried a + 1)
     if (__ballot(survmask != 0)) {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -1388,9 +1426,9 @@ __device__ __forceinline__ int pbw_sorted_call(PbWaveLds<CAP> &L, const PbParams
 // A long search handed from the chunk kernel to the workgroup kernel: ONE record per frame with everything the search needs,
 // so that the receiving workgroup starts after a single wide load (its 1024 threads copy the record into LDS side by side)
 // instead of the chain frame number -> source index -> permutation -> y that the chunk kernel went through:
-//   words [0, 492)      the frame's tables as they stand in PbWaveLds (pad, w, P, cdfA, perm, tail, q), verbatim
-//   words [492, 1004)   the committed cursors, [8][64]
-//   words [1004, ...)   PbCarry: the search state (sums <= lo are visited) and the frame's scalars
+//   words [0, 496)      the frame's tables as they stand in PbWaveLds (pad, w, P, zero row, cdfA, perm, tail, q), verbatim
+//   words [496, 1008)   the committed cursors, [8][64]
+//   words [1008, ...)   PbCarry: the search state (sums <= lo are visited) and the frame's scalars
 struct PbCarry {
     float lo, best;
     int j, nlive, cmp, suc1, suc2, bestidx;
@@ -1400,8 +1438,8 @@ struct PbCarry {
     long long f;
     float tprev, nprev;      // the last chunk's lower bound and the TEPs before it (the growth exponent for the next bound)
 };
-constexpr int kPbRecPrefix = 492, kPbRecCur = 492, kPbRecScalars = 1004, kPbRecWords = 1040;
-constexpr int kPbRecPerm = 328;       // (the permutation bytes inside the prefix: PbWaveLds::perm)
+constexpr int kPbRecPrefix = 496, kPbRecCur = 496, kPbRecScalars = 1008, kPbRecWords = 1040;
+constexpr int kPbRecPerm = 330;       // (the permutation bytes inside the prefix: PbWaveLds::perm)
 static_assert(kPbRecScalars * 4 % 8 == 0 && kPbRecScalars * 4 + sizeof(PbCarry) <= kPbRecWords * 4, "record layout");
 static_assert(offsetof(PbWaveLds<kPbWaveCap>, cdfH) == kPbRecPrefix * 4 && offsetof(PbWaveLds<kPbWaveCap>, perm) == kPbRecPerm * 4, "the record's first part is the head of PbWaveLds");
 
@@ -1456,10 +1494,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
             uint4 *const l4 = reinterpret_cast<uint4 *>(L.w);
             const uint4 a = r4[lane];
             uint4 b = make_uint4(0, 0, 0, 0);
-            if (lane < 25) b = r4[64 + lane];
+            if (lane < 26) b = r4[64 + lane];
             if constexpr (PROF) { unsigned t = a.x; asm volatile("s_waitcnt vmcnt(0)" : "+v"(t)); PBW_STAMP(kPwLoad1); }
             l4[lane] = a;
-            if (lane < 25) l4[64 + lane] = b;
+            if (lane < 26) l4[64 + lane] = b;
         }
         const PbHead &H = *reinterpret_cast<const PbHead *>(rec + kPbR1Head);
         const PbFrame Fr = H.fr;
