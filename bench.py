@@ -2,7 +2,7 @@
 """Headline benchmark: decoded frames/s (+FER) for the (128,64) CCSDS LDPC code,
 NMS-10 (+ OSD-p on the syndrome-failed frames) at Eb/N0 = 2.5 dB on synthetic AWGN frames.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload nms10_osd2|nms10_osd0|nms10|nms10_fs2|nms10_pb3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload nms10_osd2|nms10_osd0|nms10|nms10_fs2|nms10_pb3|surface_nms]
 
 One "step" = one pass of the hot path over one device-resident batch of frames:
 NMS-10 -> error counters + failed-frame compaction -> OSD-p on the failures -> OSD counters, all on the GPU
@@ -49,6 +49,9 @@ WORKLOADS = {
     # scripts/snr_sweep.py)
     "nms10_fs2": (2, 131072, "NMS-10 + FS-OSD order 2 (beta 0.1, tau_e 6.5, tau_psc 30)"),
     "nms10_pb3": (3, 131072, "NMS-10 + PB-OSD order 3 (configs[4] at one SNR point)"),
+    # the reference's own call surface of the NMS test stage: Decoding_model.__call__(inputs, labels) with NumPy in and Python
+    # lists out, exactly the body of ldpc_128_testing.py:117-131 (not a headline line: host conversions and PCIe are inside)
+    "surface_nms": (None, 131072, "stage-5 call surface: ms_test.Decoding_model(inputs, labels), NumPy in, lists of rows out"),
 }
 OSD_ALGO = {"nms10_fs2": 1, "nms10_pb3": 2}
 
@@ -303,6 +306,102 @@ def cpu_baseline(code_G, code_H, order, alpha, algo=0, snr_db=SNR_DB, seconds_ta
     return out
 
 
+def run_surface(args):
+    """--workload surface_nms: the reference's stage-5 batch body through the package's mirror of its call surface
+    (short_ldpc_decoding_osd_amd/ms_test.py = LDPC_128/Ldpc_128_testing/ms_test.py:26-70): NumPy `inputs` [B,128] f32 and
+    `labels` [B,128] int in, (fer, ber, undetected, (buffer_inputs, buffer_labels)) out, the buffers being Python lists of
+    T + 1 rows per failed frame.  Timed wall-clock around the call (host conversions, both PCIe directions and the list
+    building are the surface), at the reference's batch (1000, ldpc_128_testing.py:20) and at --batch (131 072); the device
+    part alone and the trajectory kernel are timed with events beside it."""
+    import numpy as np
+    import torch
+
+    from short_ldpc_decoding_osd_amd import Code
+    from short_ldpc_decoding_osd_amd import globalmap as GL
+    from short_ldpc_decoding_osd_amd import ms_test
+    from short_ldpc_decoding_osd_amd.runtime import default_decoder
+    from short_ldpc_decoding_osd_amd.weights import STORED_NMS1_WEIGHT, softplus32
+
+    torch.cuda.set_device(0)
+    code = Code()
+    GL.set_map('code_parameters', code)
+    GL.set_map('num_iterations', T_ITERS)
+    GL.set_map('selected_decoder_type', 'NMS-1')
+    model = ms_test.Decoding_model()
+    model.set_check_weight(STORED_NMS1_WEIGHT)
+    dec = default_decoder(code)
+    alpha = float(softplus32(STORED_NMS1_WEIGHT))
+    big = args.batch or WORKLOADS["surface_nms"][1]
+    steps = max(2, min(args.steps, 20))
+    lines = {}
+    for B in (1000, big):
+        y_d, lab_d = make_frames(dec, B, seed=20241020 + B, snr_db=args.snr)
+        inputs = y_d.cpu().numpy()
+        labels = dec.unpack_bits(lab_d).cpu().numpy()                    # [B,128] int64, one integer per bit as the reference holds them
+        for _ in range(max(1, min(args.warmup, 3))):
+            model(inputs, labels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fer, ber, und, (bi, bl) = model(inputs, labels)
+        torch.cuda.synchronize()
+        call_ms = 1e3 * (time.perf_counter() - t0) / steps
+        nfail = len(model.last_failed_index)
+        # the device part alone (inputs resident): NMS, counters, failure list, rows of the failures
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        lab_bits = dec.pack_bits(torch.from_numpy(labels).to(dec.device))
+        dev_ms, rows_ms = [], []
+        for _ in range(steps):
+            e[0].record()
+            res = dec.nms(y_d, T_ITERS, alpha, want_traj=False)
+            dec.eval_counts(res["hard"], lab_bits, res["fail"])
+            index, count = dec.compact(res["fail"])
+            e[1].record()
+            dec.nms_traj_rows(y_d, index, count, max(nfail, 1), T_ITERS, alpha)
+            e[2].record()
+            torch.cuda.synchronize()
+            dev_ms.append(e[0].elapsed_time(e[2])); rows_ms.append(e[1].elapsed_time(e[2]))
+        e[0].record()
+        for _ in range(steps):
+            dec.nms(y_d, T_ITERS, alpha, want_traj=True, want_soft=False, want_hard=False, want_fail=False)      # round 3's surface: [T][B][n] for every frame
+        e[3].record(); torch.cuda.synchronize()
+        full_traj_ms = e[0].elapsed_time(e[3]) / steps
+        row_bytes = nfail * (T_ITERS + 1) * 512
+        lines[B] = dict(frames=B, frames_per_s=B / (call_ms * 1e-3), call_ms=call_ms, device_ms=float(np.median(dev_ms)),
+                        traj_rows_kernel_ms=float(np.median(rows_ms)), failed_frames=nfail, fer=fer, ber=float(ber), undetected=und,
+                        buffer_rows=len(bi), trajectory_bytes_per_input_frame=row_bytes / B,
+                        full_trajectory_bytes_per_input_frame=T_ITERS * 512, full_trajectory_kernel_ms=full_traj_ms)
+    b = lines[big]
+    rows_ms = b["traj_rows_kernel_ms"]
+    nbytes = b["failed_frames"] * (512 + (T_ITERS + 1) * 512)          # channel row in, T + 1 rows out per failed frame
+    res = {
+        "metric": "decoded frames/sec through the reference call surface Decoding_model(inputs, labels), NMS-10 @ 2.5 dB",
+        "timed_region": "wall clock around model(inputs, labels): host conversion + H2D + kernels + D2H of the failed frames' rows + list building",
+        "value": b["frames_per_s"], "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": b["call_ms"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"surface_nms -- {WORKLOADS['surface_nms'][2]}", "code": "CCSDS (128,64)", "snr_db": args.snr,
+                   "nms_iterations": T_ITERS, "alpha": alpha, "frames_per_call": big,
+                   "note": "NOT the headline metric: host buffers cross PCIe in both directions inside the timed region"},
+        "surface": {"reference_batch_1000": lines[1000], f"batch_{big}": b},
+        "roofline": {"bound": "hbm", "kernel": "nms_qc16_kernel<ROWS> (ldpc_nms_traj_rows)", "achieved": nbytes / (rows_ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (rows_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": rows_ms, "algorithmic_bytes_per_launch": float(nbytes),
+                     "note": "the listed frames decoded again with their T + 1 rows written in the reference's buffer order; issue-bound like the decoder"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import np_oracle
+        y_np = y_d[:1000].cpu().numpy() if big >= 1000 else inputs
+        cw_np = dec.unpack_bits(lab_d[:1000].contiguous()).cpu().numpy()
+        t0 = time.perf_counter()
+        outs = np_oracle.nms_dense(y_np, code.H, T_ITERS, alpha)
+        _, _, _, idx = np_oracle.evaluate(outs[-1], cw_np, code.H)
+        np_oracle.collect_failed(outs, cw_np, idx)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = dict(value=y_np.shape[0] / dt, unit="frames/s", cores=1, kind="port",
+                                   sample=f"dense NumPy mirror of ms_test.py:99-228 + get_eval + collect_failed_output_selective on {y_np.shape[0]} frames, {dt:.1f} s")
+    print(json.dumps(res), flush=True)
+
+
 def run_rank(args):
     import numpy as np
     import torch
@@ -540,7 +639,11 @@ def run_rank(args):
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.workload == "surface_nms":
+        if args.gpus != 1:
+            raise SystemExit("bench.py --workload surface_nms is a one-GPU, one-process measurement of the reference call surface")
+        run_surface(args)
+    elif args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args, argv)
     else:
         run_rank(args)

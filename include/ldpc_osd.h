@@ -136,6 +136,18 @@ int ldpc_nms_decode(ldpc_ctx *ctx, const float *d_llr, int64_t B, int32_t T, con
                     float w_out, float *d_soft, float *d_traj, uint64_t *d_hard, uint8_t *d_fail, int32_t kernel,
                     void *stream);
 
+/* The trajectories of LISTED frames only, in the layout the reference buffers them: collect_failed_output_selective,
+ * ms_test.py:55-64 (driven by Decoding_model.call :30-34 with the index of get_eval :51) -- T + 1 rows per failed
+ * frame, row 0 the channel values (soft_output_list[0]), row t the posterior after iteration t.
+ *   d_index / d_count  the frame list as ldpc_compact writes it; the number of frames is min(*d_count, F), read ON THE
+ *                      DEVICE; F is the capacity of d_rows
+ *   d_rows             [F][T+1][n] f32
+ * The frames are decoded again (same kernel, same arithmetic: every row equals the corresponding row of
+ * ldpc_nms_decode's d_traj); nothing else is written.  At 2.5 dB a quarter of the frames fail: 1.4 KiB of rows per
+ * input frame instead of the 5 KiB of a full [T][B][n] trajectory.                                                   */
+int ldpc_nms_traj_rows(ldpc_ctx *ctx, const float *d_llr, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                       int32_t T, const float *alpha, float w_in, float w_out, float *d_rows, int32_t kernel, void *stream);
+
 /* Error statistics, Decoding_model.get_eval, ms_test.py:36-54.
  * d_counts[5] += {frames, frames_in_error, bit_errors, undetected, syndrome_failures}.
  * The caller zeroes d_counts; d_fail may be NULL (then undetected/syndrome are not counted). */

@@ -19,7 +19,7 @@ SYMBOLS = (
     "ldpc_code_from_alist", "ldpc_code_from_dense", "ldpc_code_destroy", "ldpc_code_dims",
     "ldpc_code_get_H", "ldpc_code_get_G", "ldpc_gf2elim_host", "ldpc_tep_table", "ldpc_tep_table_fs", "ldpc_crc32c",
     "ldpc_ctx_create", "ldpc_ctx_destroy", "ldpc_ctx_nms_kernel", "ldpc_ctx_get_pb_tuning", "ldpc_ctx_set_pb_tuning",
-    "ldpc_nms_decode", "ldpc_eval_counts", "ldpc_compact", "ldpc_pack_bits", "ldpc_unpack_bits",
+    "ldpc_nms_decode", "ldpc_nms_traj_rows", "ldpc_eval_counts", "ldpc_compact", "ldpc_pack_bits", "ldpc_unpack_bits",
     "ldpc_osd_reserve", "ldpc_osd_reserve_stream", "ldpc_osd_release_stream", "ldpc_osd_index_errors", "ldpc_osd_ge", "ldpc_osd_front", "ldpc_osd_search", "ldpc_osd_decode", "ldpc_osd_tep_eval", "ldpc_osd_counts",
     "ldpc_hosd_pattern_teps", "ldpc_hosd_front", "ldpc_hosd_search",
     "ldpc_pipeline_run", "ldpc_pipeline_timing",
@@ -95,6 +95,7 @@ def load():
         "ldpc_ctx_set_pb_tuning": (C.c_int, [vp, C.POINTER(PbTuning)]),
         # device entry points: device pointers travel as integers (tensor.data_ptr())
         "ldpc_nms_decode": (C.c_int, [vp, vp, i64, i32, C.POINTER(f32), f32, f32, vp, vp, vp, vp, i32, vp]),
+        "ldpc_nms_traj_rows": (C.c_int, [vp, vp, vp, vp, i64, i32, C.POINTER(f32), f32, f32, vp, i32, vp]),
         "ldpc_eval_counts": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
         "ldpc_compact": (C.c_int, [vp, vp, i64, vp, vp, vp]),
         "ldpc_pack_bits": (C.c_int, [vp, vp, i32, i64, vp, vp]),

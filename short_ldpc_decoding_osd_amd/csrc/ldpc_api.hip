@@ -103,6 +103,17 @@ int ldpc_nms_decode(ldpc_ctx *ctx, const float *d_llr, int64_t B, int32_t T, con
     return launch_nms(ctx, d_llr, B, T, alpha, w_in, w_out, d_soft, d_traj, d_hard, d_fail, kernel, (hipStream_t)stream);
 }
 
+int ldpc_nms_traj_rows(ldpc_ctx *ctx, const float *d_llr, const int32_t *d_index, const int32_t *d_count, int64_t F, int32_t T,
+                       const float *alpha, float w_in, float w_out, float *d_rows, int32_t kernel, void *stream)
+{
+    if (!ctx || F < 0 || ((!d_llr || !d_index || !d_rows) && F > 0)) return fail(LDPC_E_ARG, "ldpc_nms_traj_rows: bad arguments");
+    if (T < 0 || T > kMaxIters) return fail(LDPC_E_ARG, "ldpc_nms_traj_rows: T=%d outside 0..%d", T, kMaxIters);
+    if (T > 0 && !alpha) return fail(LDPC_E_ARG, "ldpc_nms_traj_rows: alpha is NULL");
+    if (!d_count) return fail(LDPC_E_ARG, "ldpc_nms_traj_rows: d_count is NULL (the number of listed frames is device data)");
+    if (F == 0) return LDPC_OK;
+    return launch_nms(ctx, d_llr, F, T, alpha, w_in, w_out, nullptr, nullptr, nullptr, nullptr, kernel, (hipStream_t)stream, d_index, d_count, d_rows);
+}
+
 int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
 {
     if (!ctx || !p) return fail(LDPC_E_ARG, "ldpc_pipeline_run: null argument");

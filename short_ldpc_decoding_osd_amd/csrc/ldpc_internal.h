@@ -77,7 +77,8 @@ int64_t hosd_pattern_teps(int nseg, const int32_t *bounds, const int32_t *patter
 
 // launchers (one per .hip file)
 int launch_nms(ldpc_ctx *ctx, const float *d_llr, int64_t B, int T, const float *alpha, float w_in, float w_out,
-               float *d_soft, float *d_traj, uint64_t *d_hard, uint8_t *d_fail, int kernel, hipStream_t st);
+               float *d_soft, float *d_traj, uint64_t *d_hard, uint8_t *d_fail, int kernel, hipStream_t st,
+               const int32_t *d_index = nullptr, const int32_t *d_count = nullptr, float *d_rows = nullptr);
 int probe_dpp(bool *ror_up, int *wave_rol_dir);
 int osd_search_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
                        const uint8_t *d_perm, const uint64_t *d_parity, const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric,

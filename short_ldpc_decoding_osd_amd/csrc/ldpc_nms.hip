@@ -42,11 +42,14 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+// (index / count / rows: the failed-frame form, ldpc_nms_traj_rows -- frame f of the launch is llr[index[f]], f < min(*count, B),
+//  and the only output is rows[f][0..T][n]: row 0 the channel values, row t the posterior after iteration t)
 __global__ __launch_bounds__(256) void nms_generic_kernel(
     const float *__restrict__ llr, long long B, int T, AlphaArg alpha, float w_in, float w_out,
     float *__restrict__ soft, float *__restrict__ traj, unsigned long long *__restrict__ hard,
     unsigned char *__restrict__ fail, const int *__restrict__ chk_ptr, const int *__restrict__ chk_var,
-    const int *__restrict__ var_ptr, const int *__restrict__ var_edge, int n, int m, int E)
+    const int *__restrict__ var_ptr, const int *__restrict__ var_edge, int n, int m, int E,
+    const int *__restrict__ index, const int *__restrict__ count, float *__restrict__ rows)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -55,11 +58,14 @@ __global__ __launch_bounds__(256) void nms_generic_kernel(
     float *yb = tot + n;
     const int words = (n + 63) >> 6;
 
+    if (count) { const long long c = *count; B = c < B ? c : B; }
     for (long long f = (long long)blockIdx.x * 4 + wave; f < B; f += (long long)gridDim.x * 4) {
+        const long long src = index ? index[f] : f;
         for (int v = lane; v < n; v += 64) {
-            float y = llr[f * n + v];
+            float y = llr[src * n + v];
             yb[v] = y;
             tot[v] = y;  // T == 0: the posterior is the channel value
+            if (rows) rows[(f * (T + 1)) * n + v] = y;
         }
         for (int e = lane; e < E; e += 64) cv[e] = 0.0f;
         wave_lds_fence();
@@ -94,12 +100,13 @@ __global__ __launch_bounds__(256) void nms_generic_kernel(
                 }
             }
             wave_lds_fence();
-            if (traj || it == T - 1) {
+            if (traj || rows || it == T - 1) {
                 for (int v = lane; v < n; v += 64) {
                     float acc = 0.0f;
                     for (int q = var_ptr[v]; q < var_ptr[v + 1]; ++q) acc = acc + cv[var_edge[q]];
                     float o = acc + w_out * yb[v];
                     if (traj) traj[((long long)it * B + f) * n + v] = o;
+                    if (rows) rows[(f * (T + 1) + it + 1) * n + v] = o;
                     if (it == T - 1) tot[v] = o;
                 }
                 wave_lds_fence();
@@ -270,28 +277,46 @@ __device__ __forceinline__ int syndrome_row(const int (&h)[8])
     return s;
 }
 
-template <bool UP>
+// ROWS = false: the decoder (soft / traj / hard / fail of frames 0 .. B).  ROWS = true: the failed-frame form of
+// collect_failed_output_selective (ms_test.py:55-64): frame f of the launch is llr[index[f]], f < min(*count, B), and the only
+// output is traj[f][0..T][128] -- row 0 the channel values, row t the posterior after iteration t: the reference's buffer order.
+// The reference keeps T + 1 rows of the FAILED frames only; writing [T][B][128] for all frames (round 3's surface) was
+// 5.1 KiB per input frame against 1.4 KiB at 2.5 dB.  Same arithmetic, same order: the rows equal the full trajectory's.
+template <bool UP, bool ROWS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void nms_qc16_kernel(const float *__restrict__ llr, long long B, int T,
                                                        AlphaArg alpha, float w_in, float w_out,
                                                        float *__restrict__ soft, float *__restrict__ traj,
                                                        unsigned long long *__restrict__ hard,
-                                                       unsigned char *__restrict__ fail)
+                                                       unsigned char *__restrict__ fail,
+                                                       const int *__restrict__ index = nullptr, const int *__restrict__ count = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, r = lane >> 4;
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long f = wave_id * 4 + r;
+    if constexpr (ROWS) {
+        const long long c = *count;
+        B = c < B ? c : B;
+        if (wave_id * 4 >= B) return;      // (the grid is sized for the capacity; the count is device data)
+    }
     const bool live = f < B;
     const long long fl = live ? f : B - 1;  // dead rows compute on a valid frame, store nothing
 
     float y[8], yin[8], yout[8], S[8], cv[32];
-    const float *src = llr + fl * 128 + j;
+    const float *src = llr + (ROWS ? (long long)index[fl] : fl) * 128 + j;
 #pragma unroll
     for (int bc = 0; bc < 8; ++bc) {
         y[bc] = src[bc * 16];
         yin[bc] = y[bc] * w_in;
         yout[bc] = w_out * y[bc];
         S[bc] = 0.0f;
+    }
+    if constexpr (ROWS) {
+        if (live) {
+            float *dst = traj + fl * (long long)(T + 1) * 128 + j;
+#pragma unroll
+            for (int bc = 0; bc < 8; ++bc) dst[bc * 16] = y[bc];
+        }
     }
 #pragma unroll
     for (int e = 0; e < 32; ++e) cv[e] = 0.0f;
@@ -309,8 +334,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         check_row<2, UP>(cv, tot, a_it, signv);
         check_row<3, UP>(cv, tot, a_it, signv);
         var_sums<UP>(cv, j, S);
-        if (traj) {
-            float *dst = traj + ((long long)it * B + fl) * 128 + j;
+        if (ROWS || traj) {
+            float *dst = ROWS ? traj + (fl * (long long)(T + 1) + it + 1) * 128 + j : traj + ((long long)it * B + fl) * 128 + j;
             if (live) {
 #pragma unroll
                 for (int bc = 0; bc < 8; ++bc) dst[bc * 16] = S[bc] + yout[bc];
@@ -318,6 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
 
+    if constexpr (ROWS) return;
     float out[8];
     int h[8];
 #pragma unroll
@@ -378,7 +404,8 @@ int probe_dpp(bool *ror_up, int *wave_rol_dir)
 }
 
 int launch_nms(ldpc_ctx *ctx, const float *d_llr, int64_t B, int T, const float *alpha, float w_in, float w_out,
-               float *d_soft, float *d_traj, uint64_t *d_hard, uint8_t *d_fail, int kernel, hipStream_t st)
+               float *d_soft, float *d_traj, uint64_t *d_hard, uint8_t *d_fail, int kernel, hipStream_t st,
+               const int32_t *d_index, const int32_t *d_count, float *d_rows)
 {
     const ldpc_code &c = ctx->code;
     if (kernel == LDPC_NMS_AUTO) kernel = c.qc16_ccsds ? LDPC_NMS_QC16 : LDPC_NMS_GENERIC;
@@ -389,12 +416,19 @@ int launch_nms(ldpc_ctx *ctx, const float *d_llr, int64_t B, int T, const float 
     auto *hard = reinterpret_cast<unsigned long long *>(d_hard);
     if (kernel == LDPC_NMS_QC16) {
         const unsigned blocks = (unsigned)((B + 15) / 16);
-        if (ctx->dpp_ror_up)
-            hipLaunchKernelGGL(nms_qc16_kernel<true>, dim3(blocks), dim3(256), 0, st, d_llr, (long long)B, T, a, w_in,
-                               w_out, d_soft, d_traj, hard, d_fail);
+        if (d_rows) {
+            if (ctx->dpp_ror_up)
+                hipLaunchKernelGGL((nms_qc16_kernel<true, true>), dim3(blocks), dim3(256), 0, st, d_llr, (long long)B, T, a, w_in, w_out,
+                                   (float *)nullptr, d_rows, (unsigned long long *)nullptr, (unsigned char *)nullptr, d_index, d_count);
+            else
+                hipLaunchKernelGGL((nms_qc16_kernel<false, true>), dim3(blocks), dim3(256), 0, st, d_llr, (long long)B, T, a, w_in, w_out,
+                                   (float *)nullptr, d_rows, (unsigned long long *)nullptr, (unsigned char *)nullptr, d_index, d_count);
+        } else if (ctx->dpp_ror_up)
+            hipLaunchKernelGGL((nms_qc16_kernel<true, false>), dim3(blocks), dim3(256), 0, st, d_llr, (long long)B, T, a, w_in,
+                               w_out, d_soft, d_traj, hard, d_fail, (const int *)nullptr, (const int *)nullptr);
         else
-            hipLaunchKernelGGL(nms_qc16_kernel<false>, dim3(blocks), dim3(256), 0, st, d_llr, (long long)B, T, a, w_in,
-                               w_out, d_soft, d_traj, hard, d_fail);
+            hipLaunchKernelGGL((nms_qc16_kernel<false, false>), dim3(blocks), dim3(256), 0, st, d_llr, (long long)B, T, a, w_in,
+                               w_out, d_soft, d_traj, hard, d_fail, (const int *)nullptr, (const int *)nullptr);
     } else if (kernel == LDPC_NMS_GENERIC) {
         const size_t lds = sizeof(float) * 4 * ((size_t)c.E + 2 * (size_t)c.n);
         if (lds > 160 * 1024) return fail(LDPC_E_UNSUPPORTED, "code too large for the generic NMS kernel (%zu B of LDS)", lds);
@@ -410,7 +444,7 @@ int launch_nms(ldpc_ctx *ctx, const float *d_llr, int64_t B, int T, const float 
         const unsigned blocks = (unsigned)(want < 8192 ? want : 8192);
         hipLaunchKernelGGL(nms_generic_kernel, dim3(blocks), dim3(256), lds, st, d_llr, (long long)B, T, a, w_in, w_out,
                            d_soft, d_traj, hard, d_fail, ctx->d_chk_ptr, ctx->d_chk_var, ctx->d_var_ptr,
-                           ctx->d_var_edge, c.n, c.m, c.E);
+                           ctx->d_var_edge, c.n, c.m, c.E, d_index, d_count, d_rows);
     } else {
         return fail(LDPC_E_ARG, "unknown NMS kernel id %d", kernel);
     }

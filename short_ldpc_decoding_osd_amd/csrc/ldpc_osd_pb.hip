@@ -337,7 +337,7 @@ struct PbHead {
     float hbest;
     int nhead, hsuc2, hbestidx;
 };
-constexpr int kPbR1Zero = 256, kPbR1Cdf = 258, kPbR1Perm = 326, kPbR1Copy = 360, kPbR1Head = 360, kPbR1Words = 384;
+constexpr int kPbR1Zero = 256, kPbR1Cdf = 258, kPbR1Perm = 326, kPbR1Head = 360, kPbR1Words = 384;     // (words [0, kPbR1Head) are copied into LDS)
 static_assert(kPbR1Head * 4 % 8 == 0 && kPbR1Head * 4 + sizeof(PbHead) <= kPbR1Words * 4, "record layout");
 
 template <class LDS>
@@ -2160,7 +2160,7 @@ __device__ __noinline__ void coop_solo_range(PbCoopLds<NW> &L)
 {
     constexpr int CAP = kPbWaveCap;
     const int lane = threadIdx.x & 63;
-    unsigned long long pt[kPwSlots], plast = 0;
+    unsigned long long pt[kPwSlots];
     const PbParams P = L.sP;
     const PbFrame Fr = L.su.fr;
     const u64 d0 = L.su.d0;

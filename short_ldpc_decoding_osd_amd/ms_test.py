@@ -6,11 +6,14 @@
     model = Decoding_model()
     fer, ber, undetected, (buffer_inputs, buffer_labels) = model(inputs, labels)
 
-Same names, arity and return shapes as the reference; tensors come back as NumPy arrays.
+Same names, arity and return shapes as the reference; tensors come back as NumPy arrays, the two row buffers of
+``Decoding_model.call`` as ``RowBuffer`` sequences (list-like views of one array each).
 The learned weights are plain attributes holding the *stored* (pre-softplus) values, as in
 the TF checkpoint (ms_test.py:83, :207-208): ``layer.shared_check_weight`` etc.
 """
 from __future__ import annotations
+
+import collections.abc
 
 import numpy as np
 import torch
@@ -18,6 +21,46 @@ import torch
 from . import globalmap as GL
 from .runtime import default_decoder
 from .weights import softplus32 as _softplus32
+
+
+class RowBuffer(collections.abc.Sequence):
+    """The list of rows ``Decoding_model.call`` returns (buffer_inputs / buffer_labels, ms_test.py:55-64), held as ONE 2-D array
+    instead of a Python list of row objects: it has ``len``, indexing, slicing and iteration like the reference's lists, so
+    ``np.stack(buf)``, ``buf[k]``, ``for row in buf`` and the reference's flattening comprehension all work -- but building
+    370 k row objects per 131 072-frame batch (and a 380 MB int64 copy of the labels repeated T + 1 times) was 60 % of the
+    call.  ``repeat`` > 1: row k is ``array[k // repeat]`` (the label of a failed frame stands for its T + 1 rows).
+    ``materialize()`` returns the plain 2-D array (with the repeats written out)."""
+
+    def __init__(self, array, repeat=1):
+        self.array, self.repeat = array, int(repeat)
+
+    def __len__(self):
+        return self.array.shape[0] * self.repeat
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        if not 0 <= k < len(self):
+            raise IndexError(k)
+        return self.array[k // self.repeat]
+
+    def __iter__(self):
+        if self.repeat == 1:
+            return iter(self.array)
+        return (self.array[k // self.repeat] for k in range(len(self)))
+
+    def materialize(self):
+        return self.array if self.repeat == 1 else np.repeat(self.array, self.repeat, axis=0)
+
+    @staticmethod
+    def concatenate(parts):
+        """One buffer from several (postprocess_failure_cases): arrays concatenated, repeats written out only if they differ."""
+        parts = list(parts)
+        if parts and all(isinstance(p, RowBuffer) for p in parts) and len({p.repeat for p in parts}) == 1:
+            return RowBuffer(np.concatenate([p.array for p in parts], axis=0), parts[0].repeat)
+        return [row for p in parts for row in p]
 
 
 class Decoder_Layer:
@@ -88,8 +131,15 @@ class Decoding_model:
         self.layer.shared_check_weight = np.full([1], stored_value, dtype=np.float32)
 
     def call(self, inputs, labels):
+        """``(fer, ber, undetected, (buffer_inputs, buffer_labels))`` of one batch (ms_test.py:30-34).
+
+        Device sequence: NMS-T (posterior, hard words, syndrome flags -- NO trajectory) -> error counters -> failed-frame
+        list -> the T + 1 rows of the FAILED frames only (``ldpc_nms_traj_rows``: the listed frames decoded again, rows in
+        the reference's buffer order) -> one device-to-host copy of [F, T+1, n].  Round 3 wrote the [T][B][n] trajectory
+        of every frame (5 KiB per input frame) and gathered the failures afterwards; the reference keeps T + 1 rows of the
+        failed frames only (collect_failed_output_selective, :55-64): 1.4 KiB per input frame at 2.5 dB."""
         layer = self.layer
-        dec, y, res = layer._device_run(inputs, want_traj=True)
+        dec, y, res = layer._device_run(inputs, want_traj=False)
         if isinstance(labels, torch.Tensor):
             lab_t = labels.to(device=dec.device, dtype=torch.int64).contiguous()
             labels_np = None
@@ -97,26 +147,29 @@ class Decoding_model:
             labels_np = np.ascontiguousarray(labels, dtype=np.int64)
             lab_t = torch.from_numpy(labels_np).to(dec.device)
         label_bits = dec.pack_bits(lab_t)
-        counts = dec.eval_counts(res["hard"], label_bits, res["fail"]).cpu().numpy()
+        counts_d = dec.eval_counts(res["hard"], label_bits, res["fail"])
         index, count = dec.compact(res["fail"])
-        nfail = int(count.cpu()[0])
-        idx = index[:nfail].to(torch.int64)
         B, n = y.shape
+        T = layer.num_iterations
+        alpha, w_in, w_out = layer.effective_weights()
+        host = torch.cat([counts_d, count.to(torch.int64)]).cpu().numpy()      # ONE small copy: the five counters and the failure count
+        counts, nfail = host[:5], int(host[5])
+        rows_np = np.zeros((0, n), np.float32)
+        idx_np = np.zeros((0,), np.int64)
+        if nfail:
+            rows = dec.nms_traj_rows(y, index, count, nfail, T, alpha, w_in, w_out)      # [F, T+1, n]
+            rows_np = rows.reshape(nfail * (T + 1), n).cpu().numpy()
+            idx_np = index[:nfail].cpu().numpy().astype(np.int64)
         fer = float(counts[1]) / B                       # 1 - len(success_index)/B       (:52)
         ber = float(counts[2]) / (B * n)                 # (:53)
         undetected = int(counts[3])                      # len(not_in_success_index)      (:46-54)
-        # collect_failed_output_selective (:55-64): T+1 rows per failed frame, row 0 = channel
-        T = layer.num_iterations
-        rows = torch.cat([y[idx].unsqueeze(1), res["traj"][:, idx, :].permute(1, 0, 2)], dim=1)  # [F, T+1, n]
-        rows_np = rows.reshape(nfail * (T + 1), n).cpu().numpy()
         if labels_np is None:
             labels_np = lab_t.cpu().numpy()
-        lab_rows = np.repeat(labels_np[idx.cpu().numpy()], T + 1, axis=0)
-        buffer_inputs = [r for r in rows_np]
-        buffer_labels = [r for r in lab_rows]
+        buffer_inputs = RowBuffer(rows_np)               # T+1 rows per failed frame, row 0 = channel (:55-64)
+        buffer_labels = RowBuffer(labels_np[idx_np], repeat=T + 1)
         self.last_counts = dict(zip(("frames", "frame_err", "bit_err", "undetected", "synd_fail"),
                                     (int(c) for c in counts)))
-        self.last_failed_index = idx.cpu().numpy()
+        self.last_failed_index = idx_np
         return fer, ber, undetected, (buffer_inputs, buffer_labels)
 
     __call__ = call
@@ -145,9 +198,7 @@ class Decoding_model:
 
     def postprocess_failure_cases(self, buffer):
         """Flatten the per-batch lists (ms_test.py:66-70)."""
-        buffer_inputs = [j for i in buffer[0] for j in i]
-        buffer_labels = [j for i in buffer[1] for j in i]
-        return buffer_inputs, buffer_labels
+        return RowBuffer.concatenate(buffer[0]), RowBuffer.concatenate(buffer[1])
 
 
 def calculation_loss(soft_output, labels):
@@ -161,8 +212,12 @@ def save_decoded_data(updated_buffer, file_dir, snr, log_filename, list_length):
     """Per-iteration mean CE to the log, then the retest TFRecord (ms_test.py:251-272)."""
     from . import data_generating as Data_gen
 
-    info = np.stack(updated_buffer[0]) if len(updated_buffer[0]) else np.zeros((0, 0), np.float32)
-    label = np.stack(updated_buffer[1]) if len(updated_buffer[1]) else np.zeros((0, 0), np.int64)
+    def as_array(buf, dtype):
+        if isinstance(buf, RowBuffer):
+            return buf.materialize()
+        return np.stack(buf) if len(buf) else np.zeros((0, 0), dtype)
+
+    info, label = as_array(updated_buffer[0], np.float32), as_array(updated_buffer[1], np.int64)
     CE_loss_list = []
     tested = 0
     for i in range(list_length):

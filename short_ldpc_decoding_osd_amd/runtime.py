@@ -87,6 +87,18 @@ class Decoder:
                    "ldpc_nms_decode")
         return out
 
+    def nms_traj_rows(self, llr, index, count, F, T, alpha, w_in=1.0, w_out=1.0, kernel=_lib.NMS_AUTO, out=None):
+        """Rows of the listed frames only (collect_failed_output_selective, ms_test.py:55-64): [F, T+1, n] f32, row 0 the
+        channel values, row t the posterior after iteration t.  ``index`` / ``count``: the list as ``compact`` wrote it;
+        ``F``: how many rows to allocate for (the launch decodes min(count, F) frames)."""
+        self._chk(llr, torch.float32, (self.n,), "llr")
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=np.float32), (max(T, 1),)))
+        rows = out if out is not None else self.empty((max(int(F), 1), T + 1, self.n), torch.float32)
+        _lib.check(self.L.ldpc_nms_traj_rows(self._ctx, _ptr(llr), _ptr(index), _ptr(count), int(F), T,
+                                             a.ctypes.data_as(C.POINTER(C.c_float)), float(w_in), float(w_out), _ptr(rows),
+                                             int(kernel), self._stream()), "ldpc_nms_traj_rows")
+        return rows
+
     # ------------------------------------------------------------------ statistics / plumbing kernels
     def eval_counts(self, hard, label_bits, fail=None, counts=None):
         """counts[5] += {frames, frame_err, bit_err, undetected, synd_fail} (int64 tensor)."""

@@ -188,3 +188,40 @@ def test_decoding_model_surface(dec):
     assert len(lst) == 11 and all(np.array_equal(a, b) for a, b in zip(lst, outs))
     f2, b2, u2, index = model.get_eval(lst, cw)
     assert (f2, u2) == (fer, und) and np.array_equal(index[:, 0], idx)
+
+
+@pytest.mark.parametrize("kernel", ["auto", "generic"])
+def test_traj_rows_of_listed_frames(dec, kernel):
+    """ldpc_nms_traj_rows (collect_failed_output_selective, ms_test.py:55-64): T + 1 rows per LISTED frame, row 0 the channel
+    values, row t the posterior after iteration t -- equal to the rows of the full [T][B][n] trajectory bit for bit, for both
+    NMS kernels; the number of frames is device data (count), the capacity may be larger, an empty list writes nothing."""
+    from short_ldpc_decoding_osd_amd import _lib
+    kid = {"auto": _lib.NMS_AUTO, "generic": _lib.NMS_GENERIC}[kernel]
+    T, alpha = 10, np_oracle.softplus(-0.048)
+    y, cw = _frames(dec, 2.5, 1003, seed=31)
+    yd = torch.from_numpy(y).to(dec.device)
+    res = dec.nms(yd, T, alpha, want_traj=True, kernel=kid)
+    index, count = dec.compact(res["fail"])
+    nf = int(count.cpu()[0])
+    assert 100 < nf < 600
+    rows = dec.nms_traj_rows(yd, index, count, nf + 37, T, alpha, kernel=kid, out=torch.full((nf + 37, T + 1, 128), -7.0, device=dec.device))
+    torch.cuda.synchronize()
+    idx = index[:nf].long()
+    want = torch.cat([yd[idx].unsqueeze(1), res["traj"][:, idx, :].permute(1, 0, 2)], dim=1)
+    assert torch.equal(rows[:nf], want)
+    assert (rows[nf:] == -7.0).all()                                       # capacity beyond the count: untouched
+    # the C oracle's trajectory (soft outputs per iteration) for a few of them
+    soft_o = c_oracle.nms(dec.code.H, y[idx[:8].cpu().numpy()], T, alpha)
+    assert np.array_equal(rows[:8, T].cpu().numpy(), soft_o)
+    # a caller-made list in another order, with a repeated frame; NMS-3 style bit weights
+    lst = torch.tensor([5, 0, 1002, 5], dtype=torch.int32, device=dec.device)
+    cnt = torch.tensor([4], dtype=torch.int32, device=dec.device)
+    r2 = dec.nms_traj_rows(yd, lst, cnt, 4, 3, [0.5, 0.6, 0.7], w_in=0.9, w_out=1.1, kernel=kid)
+    full = dec.nms(yd, 3, [0.5, 0.6, 0.7], w_in=0.9, w_out=1.1, want_traj=True, kernel=kid)["traj"]
+    torch.cuda.synchronize()
+    for k, f in enumerate([5, 0, 1002, 5]):
+        assert torch.equal(r2[k, 0], yd[f]) and torch.equal(r2[k, 1:], full[:, f, :])
+    zero = torch.zeros(1, dtype=torch.int32, device=dec.device)
+    r3 = dec.nms_traj_rows(yd, lst, zero, 4, 3, 0.5, kernel=kid, out=torch.full((4, 4, 128), 3.0, device=dec.device))
+    torch.cuda.synchronize()
+    assert (r3 == 3.0).all()
