@@ -448,18 +448,28 @@ def run_rank(args):
     # step (the driver-timed step was 6 % above the kernel sum).  Steps beyond whole rotations, several
     # streams, or a failed capture run eagerly; the JSON line says which.
     graph, timed_region = None, "eager ldpc_pipeline_run calls"
+    graph_info = {"graph_steps_per_launch": 0, "graph_branches": 0, "overlapped": len(streams) > 1}
+    rpg = 1
     if args.graph and len(streams) == 1 and args.steps >= nb:
         try:
             side = torch.cuda.Stream()
             nbr = max(1, min(args.graph_branches, nb))
             branch = [side] + [torch.cuda.Stream() for _ in range(1, nbr)]
 
-            def rotation():
+            # rotations per graph launch: a graph ends with a join of its branches, and the tail of the slowest branch of one
+            # launch does not overlap the head of the next -- with the driver's 20 steps that was five joins in 5.8 ms.  Up to
+            # 8 rotations (32 steps) go into one graph; batch i stays on branch i mod N through all of them (its buffers are
+            # reused step after step, so the branch's stream order is also the data dependence).
+            rot_total = args.steps // nb
+            rpg = max(r for r in range(1, 9) if rot_total % r == 0)
+
+            def rotation(reps=1):
                 for st in branch[1:]:
                     st.wait_stream(side)                 # fork
-                for i, p in enumerate(pipes):
-                    with torch.cuda.stream(branch[i % nbr]):
-                        p.run()
+                for _ in range(reps):
+                    for i, p in enumerate(pipes):
+                        with torch.cuda.stream(branch[i % nbr]):
+                            p.run()
                 for st in branch[1:]:
                     side.wait_stream(st)                 # join
 
@@ -472,13 +482,14 @@ def run_rank(args):
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
-                rotation()
+                rotation(rpg)
             graph = g
-            for _ in range(max(1, -(-args.warmup // nb))):      # the warm-up steps once more, as replays (a graph's first launch uploads it)
+            for _ in range(max(1, -(-args.warmup // (nb * rpg)))):      # the warm-up steps once more, as replays (a graph's first launch uploads it)
                 g.replay()
             torch.cuda.synchronize()
-            timed_region = (f"HIP graph replay, {nb} steps (one rotation over the distinct batches) per graph launch, "
+            timed_region = (f"HIP graph replay, {nb * rpg} steps ({rpg} rotation(s) over the {nb} distinct batches) per graph launch, "
                             f"{nbr} parallel branch(es)")
+            graph_info = {"graph_steps_per_launch": nb * rpg, "graph_branches": nbr, "overlapped": nbr > 1}
         except Exception as exc:   # noqa: BLE001
             graph = None
             timed_region = f"eager ldpc_pipeline_run calls (graph capture failed: {type(exc).__name__})"
@@ -491,7 +502,7 @@ def run_rank(args):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if graph is not None:
-        for _ in range(args.steps // nb):
+        for _ in range(args.steps // (nb * rpg)):
             graph.replay()
         for k in range(args.steps - args.steps % nb, args.steps):
             run_step(k)
@@ -564,6 +575,9 @@ def run_rank(args):
     res = {
         "metric": "decoded frames/sec + FER, (128,64) LDPC NMS-10+OSD-2 @ 2.5 dB",
         "timed_region": timed_region,
+        # (machine-readable form of the above -- with parallel branches ms_per_step is a throughput reciprocal, not
+        #  a step latency; `--graph-branches 1` times one chain)
+        "timed_region_info": graph_info,
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",

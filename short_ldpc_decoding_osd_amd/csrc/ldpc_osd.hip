@@ -102,11 +102,16 @@ __device__ __forceinline__ FrontResult front_device(FrontLds &L, const float *__
     int rho = lane, idx1 = lane, idx2 = lane + 64;
     const int ns = ge_columns(C1, C2, rho, idx1, idx2, lane, nullptr);
     // ---- identify_mrb bookkeeping (pb_testing.py:276-304) --------------------------------
-    atomicOr(&L.mask[idx1 >> 5], 1u << (idx1 & 31));
-    wave_fence();
-    const unsigned m[4] = {L.mask[0], L.mask[1], L.mask[2], L.mask[3]};
-    const int rankM = below_mask(m, idx1);         // new MRB position of slot `lane`
-    const int rankL = idx2 - below_mask(m, idx2);  // new parity column of slot `lane`
+    // (no column exchange -- the 64 most reliable columns were independent: a quarter of the frames -- leaves every index
+    //  where the sort put it: the ranks are the lane numbers and the membership mask is not needed)
+    int rankM = lane, rankL = lane;
+    if (ns != 0) {
+        atomicOr(&L.mask[idx1 >> 5], 1u << (idx1 & 31));
+        wave_fence();
+        const unsigned m[4] = {L.mask[0], L.mask[1], L.mask[2], L.mask[3]};
+        rankM = below_mask(m, idx1);         // new MRB position of slot `lane`
+        rankL = idx2 - below_mask(m, idx2);  // new parity column of slot `lane`
+    }
     L.perm[rankM] = L.pi1[idx1];
     L.perm[64 + rankL] = L.pi1[idx2];
     L.colbuf[rankL] = C2;
