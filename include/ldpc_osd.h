@@ -219,7 +219,7 @@ typedef struct ldpc_osd_params {
  *                  TEPs after which a search may be handed to the workgroup kernel, chosen on the device by the number of
  *                  frames still searching after the weight-1 head (a sixteenth of them: < 128 / < 448 / < 1400 / < 3000 /
  *                  more); >= 1.  Defaults 512 / 1024 / 4096 / 8192 / 24576 (measurements: DESIGN.md 3.4).
- *   t1, t2         target size of a frame's first / later chunks in the one-wavefront kernel, 32..384 (320, 312)
+ *   t1, t2         target size of a frame's first / later chunks in the one-wavefront kernel, 32..832 (320, 600)
  *   t3             target chunk size of the workgroup kernel, 256..4096 (3072)
  *   late_min, late_maxlen, late_pct, late_div
  *                  frames beyond late_pct % of their sub-list (lists of more than late_min and fewer than late_maxlen

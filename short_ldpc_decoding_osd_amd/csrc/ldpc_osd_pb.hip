@@ -531,6 +531,14 @@ struct PbSortArgs {
     float mn, mx, c4;
     int n, order, state, stop, ntep;
 };
+// ... and of pbw_redo_range: the sums (lo, T] -- n TEPs, `done` visited before them -- once more, in chunks of 8-byte keys
+struct PbRedoArgs {
+    PbwState S;
+    PbFrame fr;
+    u64 d0;
+    float lo, T, smax, c4;
+    int done, n, order, target, state, stop, ntep;
+};
 
 constexpr int kPbMaxTie = 16;
 constexpr int kPbWaveCap = 384;   // chunk capacity of the chunk kernel (10 KiB of LDS per frame: four wavefronts per SIMD; 512 = 12 KiB = three)
@@ -564,10 +572,11 @@ struct __attribute__((aligned(16))) PbWaveLds {
             float cc[16], rc[16];
         };
         PbSortArgs sa;        // (the pass has given up on the chunk when the sorted path is called: its words are free)
+        PbRedoArgs ra;        // (read into registers on entry, written on exit: the calls in between use the words)
     };
     u64 cw[2];
 };
-static_assert(sizeof(PbSortArgs) <= 384, "the sorted path's arguments borrow the candidate words");
+static_assert(sizeof(PbSortArgs) <= 384 && sizeof(PbRedoArgs) <= 384, "the rare paths' arguments borrow the candidate words");
 
 __device__ __forceinline__ int pbw_phys(int i) { return i; }
 
@@ -705,13 +714,24 @@ __device__ __forceinline__ float pbw_rot1(float x)
 // A lane works on whatever item the list hands it, hence the cursors in LDS and the item geometry from run-time (q, lane).
 // (Round 3 kept the next-member sums in registers -- 32 VGPRs -- and took them back from the dense phase in a third sweep,
 //  "collect", ~9 instructions per item: 57 spilled registers re-read and re-written once per walk.)
-template <int CAP, bool PROF, int ROT>
+// K4 = true: the keys are written as their low words only -- 4 bytes, the positions -- and the pass recomputes a key's sum from
+// them (pbw_scan4): the same key memory then holds 2 CAP + 64 keys, and every per-chunk cost (the list pass, the probes, the
+// bound arithmetic, the reductions) is paid once per ~680 keys instead of once per ~310.  KCAP: the capacity in keys.
+// The work list is a RING of CAP + 64 entries in both forms (an entry is free once its trip has read it).
+template <int CAP, bool K4>
+struct PbwCaps {
+    static constexpr int KCAP = K4 ? 2 * CAP + 64 : CAP;      // keys of a chunk (64 more fit behind them)
+    static constexpr int RING = CAP + 64;                      // work-list entries
+};
+template <int CAP, bool PROF, int ROT, bool K4>
 __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int order, int lane,
                                         unsigned long long (&pt)[kPwSlots])
 {
+    constexpr int KCAP = PbwCaps<CAP, K4>::KCAP, RING = PbwCaps<CAP, K4>::RING;
     unsigned long long plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
-    static_assert(sizeof(L.keys) / 8 >= CAP + 64 && CAP >= 128, "a dense trip may write 63 keys past CAP");
+    static_assert(sizeof(L.keys) / (K4 ? 4 : 8) >= KCAP + 64 && CAP >= 128, "a dense trip may write 63 keys past the capacity");
+    static_assert(sizeof(L.list) / 4 >= RING, "work-list ring");
     static_assert(offsetof(PbWaveLds<CAP>, w) >= 4 && offsetof(PbWaveLds<CAP>, w) == offsetof(PbWaveLds<CAP>, pre) + 16, "the NaN sits right in front of the weights");
     unsigned *const list = L.list;      // entry: q | owner lane << 5
     const float *const w = L.w;
@@ -733,7 +753,7 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int
         };
         const auto append = [&](int q, float sv) {
             const bool pend = sv <= T;
-            const u64 act = tail <= CAP ? __ballot(pend) : 0ull;      // (more than CAP pending items: an overflow already)
+            const u64 act = tail <= RING - 64 ? __ballot(pend) : 0ull;      // (more pending items than the ring takes: an overflow already)
             if (act) {
                 const int p = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
                 if (pend) list[p] = (unsigned)q | ((unsigned)ln << 5);
@@ -781,14 +801,16 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int
     }
     PBW_STAMP(kPwSweepA);
     if (tail == 0) return cnt;
-    if (tail > CAP) return CAP + 1;
+    if (tail > RING - 64) return KCAP + 1;
     wave_fence();
+    const auto ring = [](int p) { p = p >= RING ? p - RING : p; return p >= RING ? p - RING : p; };      // (p < 3 RING: an entry is a key at least)
+    static_assert(3 * RING > KCAP + 128, "ring index");
     int head = 0;
-    while (head < tail && cnt <= CAP) {
+    while (head < tail && cnt <= KCAP) {
         if constexpr (PROF) pt[kPwTrips] += 1;
         const int e = head + lane;
         const bool has = e < tail;
-        const unsigned ent = has ? list[e] : 0u;
+        const unsigned ent = has ? list[ring(e)] : 0u;
         const int q = (int)(ent & 31u), l = (int)((ent >> 5) & 63u);
         int i, j, base, sh;
         unsigned code;
@@ -808,7 +830,7 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int
         // keys inside a chunk is irrelevant, so the second members simply follow the first ones
         const int m = a - 1;
         const float s = sbv + w[m], s2 = sbv + w[m > 0 ? m - 1 : 0], s3 = sbv + w[m > 1 ? m - 2 : 0];
-        const bool two = has && m > base + 1 && s2 <= T && cnt <= CAP - 64;      // (no second members in a trip that may end beyond CAP + 63)
+        const bool two = has && m > base + 1 && s2 <= T && cnt <= KCAP - 64;      // (no second members in a trip that may end beyond KCAP + 63)
         const int mlast = two ? m - 1 : m;
         const bool left = mlast > base + 1;                 // the item has members beyond this trip's
         const bool again = has && left && (two ? s3 : s2) <= T;
@@ -824,16 +846,23 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int
             // adjacent child if the last position can move down by one; + 1, in bits 26-27
             const unsigned g1 = (unsigned)((m < 63 && wt < order) + (m > base + 1)) << 26;
             const unsigned g2 = (unsigned)((wt < order) + (m - 1 > base + 1)) << 26;
-            L.keys[pos] = ((u64)__float_as_uint(s) << 32) | (tmpl | g1 | ((unsigned)m << sh));
-            if (two) L.keys[pos2] = ((u64)__float_as_uint(s2) << 32) | (tmpl | g2 | ((unsigned)(m - 1) << sh));
+            if constexpr (K4) {
+                unsigned *const codes = reinterpret_cast<unsigned *>(L.keys);
+                codes[pos] = tmpl | g1 | ((unsigned)m << sh);
+                if (two) codes[pos2] = tmpl | g2 | ((unsigned)(m - 1) << sh);
+            } else {
+                L.keys[pos] = ((u64)__float_as_uint(s) << 32) | (tmpl | g1 | ((unsigned)m << sh));
+                if (two) L.keys[pos2] = ((u64)__float_as_uint(s2) << 32) | (tmpl | g2 | ((unsigned)(m - 1) << sh));
+            }
             *cb = (unsigned char)(left ? mlast : 0);        // (0: exhausted -- the list pass then reads the NaN)
-            if (again) list[nt] = ent;
+            if (again) list[ring(nt)] = ent;
         }
         cnt += __popcll(act) + __popcll(act2);
         head = head + 64 < tail ? head + 64 : tail;
         tail += __popcll(more);
         wave_fence();
-        if (tail > CAP) { cnt = CAP + 1; break; }   // every entry ever listed is at least one member: more than CAP members, an overflow
+        // (the next trip appends at tail .. tail + 63 while the entries head + 64 .. tail - 1 are still unread)
+        if (tail - head > RING - 64) { cnt = KCAP + 1; break; }
     }
     PBW_STAMP(kPwDense);
     return cnt;
@@ -857,17 +886,20 @@ __device__ __forceinline__ float pb_bound_guess(float n)
 // The next chunk: walks (lo, T] for a T aimed at `target` members, 0 < n <= CAP.  Returns n and T; the chunk's keys are
 // L.keys[0..n) and the walk's cursors are committed.  -1: the range cannot be split (massively equal sums: the frame goes
 // to the list replay); 0: nothing is left to visit (NaN sums).
-template <int CAP, bool PROF, int ROT>
+// (K4: 4-byte keys, capacity 2 CAP + 64, see pbw_walk.  COMMIT = false: W.ecur keeps the cursors the chunk STARTED from -- the
+//  caller commits, pbw_cursors_load, once the chunk is judged, or puts them back, pbw_cursors_store, and redoes the range)
+template <int CAP, bool PROF, int ROT, bool K4 = false, bool COMMIT = true>
 __device__ __forceinline__ int pbw_next_chunk(PbWaveLds<CAP> &L, PbWalk &W, int order, float lo, int done, int nall, int target, int lane,
                                               float &Tout, float &tprev, float &nprev, int &nwalks, unsigned long long (&pt)[kPwSlots],
                                               float Tcap = __builtin_inff())
 {
+    constexpr int KCAP = PbwCaps<CAP, K4>::KCAP;
     const float inf = __builtin_inff();
     const float *w = L.w;
     const float m3 = (w[61] + w[62]) + w[63];
     const float want = (float)(done + target);
     float Tl = lo, Th = inf;
-    float T = nall - done <= CAP ? inf : m3 * pb_bound_guess(want);
+    float T = nall - done <= KCAP ? inf : m3 * pb_bound_guess(want);
     if (tprev > 0.0f && nprev > 0.0f && lo > tprev && (float)done > nprev && T < inf) {   // growth exponent of the last two bounds
         const float pe = (__builtin_amdgcn_logf((float)done) - __builtin_amdgcn_logf(nprev)) / (__builtin_amdgcn_logf(lo) - __builtin_amdgcn_logf(tprev));
         if (pe > 1.5f && pe < 20.0f) T = lo * __builtin_amdgcn_exp2f((__builtin_amdgcn_logf(want) - __builtin_amdgcn_logf((float)done)) / pe);
@@ -879,10 +911,10 @@ __device__ __forceinline__ int pbw_next_chunk(PbWaveLds<CAP> &L, PbWalk &W, int 
     float T_ok = lo;
     unsigned a_ok[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < 48; ++it) {
-        cnt = pbw_walk<CAP, PROF, ROT>(L, T, cnt, order, lane, pt);
+        cnt = pbw_walk<CAP, PROF, ROT, K4>(L, T, cnt, order, lane, pt);
         ++nwalks;
         bool over = false;
-        if (cnt > CAP) {
+        if (cnt > KCAP) {
             if (c_ok > 0) break;
             over = true;
             Th = T;
@@ -920,7 +952,7 @@ __device__ __forceinline__ int pbw_next_chunk(PbWaveLds<CAP> &L, PbWalk &W, int 
     }
     if (c_ok == 0) { pbw_cursors_store<CAP>(L, W.ecur, lane); return -1; }
     if (cnt != c_ok) pbw_cursors_store<CAP>(L, a_ok, lane);   // an overflow (or a dead end) after a usable shorter chunk: back to that one
-    pbw_cursors_load<CAP>(L, W.ecur, lane);                     // commit
+    if constexpr (COMMIT) pbw_cursors_load<CAP>(L, W.ecur, lane);                     // commit
     tprev = lo; nprev = (float)done;
     Tout = T_ok;
     return c_ok;
@@ -1151,6 +1183,244 @@ __device__ __forceinline__ int pbw_scan_chunk(PbWaveLds<CAP> &L, const PbParams 
     // ---- commit
     if (nbefore > 0) {
         const u64 bk = L.rk[nbefore - 1];
+        const PbTep t = pbw_tep((unsigned)bk);
+        u64 E = 1ull << t.p0;
+        if (t.wt > 1) E |= 1ull << t.p1;
+        if (t.wt > 2) E |= 1ull << t.p2;
+        S.best = L.rc[nbefore - 1]; S.bestD = parity(t); S.bestE = E;
+        S.bestidx = S.j + rank_best + 1;
+    }
+    S.suc2 += nbefore;
+    if (reason) {
+        S.cmp += 2 * (rank_stop + 1);             // (the frontier never holds a single entry here: no one-comparison pops)
+        S.suc1 += reason == 1 ? rank_stop : rank_stop + 1;
+        stop = reason; ntep = S.j + rank_stop + 1;
+        return 1;
+    }
+    S.cmp += 2 * n; S.suc1 += n;
+    S.j += n; S.nlive += deltot;
+    return 0;
+}
+
+// pbw_scan_chunk for a chunk of 4-BYTE keys (pbw_walk<K4>: up to 2 CAP + 64 of them): the same sort-free pass, with a key's
+// sum recomputed from its positions wherever it is needed -- (w[p0] + w[p1]) + w[p2], the order the walk formed it in, three LDS
+// reads and two adds -- and NO key kept in registers: the ordinary chunk reads each key once; the rare paths (a rule fires,
+// improvement candidates) read them again.  Same results as pbw_scan_chunk on the same keys; -1 leaves the state untouched and
+// the caller redoes the chunk's sum range with 8-byte keys (pbw_redo_range).
+template <int CAP>
+__device__ __forceinline__ int pbw_scan4(PbWaveLds<CAP> &L, const PbParams &P, const PbFrame &Fr, u64 d0, int n, float mn, float mx, int lane,
+                                         PbwState &S, int &stop, int &ntep)
+{
+    constexpr int STEP = 2;
+    if (S.nlive <= 1) return -1;      // (the first chunk of a frame without its head: one entry in the frontier)
+    const float best0 = S.best;
+    float r_safe;                     // rule 1 by probes (pbw_scan_chunk)
+    {
+        const float rp = lane == 63 ? mx : mn + (mx - mn) * ((float)(lane + 1) * (1.0f / 64.0f));
+        float w1;
+        const float bs = pb_promising_bs(rp, best0, Fr, P.c4, L.cdfA, L.cdfH, w1);
+        const u64 unsafe = ~__ballot((double)bs > Fr.p_t_pro * 1.001);
+        const int u = unsafe ? __builtin_ctzll(unsafe) : 64;
+        r_safe = u == 0 ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rp), u - 1));
+    }
+    const unsigned *const codes = reinterpret_cast<const unsigned *>(L.keys);
+    const char *const Pb = reinterpret_cast<const char *>(L.P);
+    const char *const wb = reinterpret_cast<const char *>(L.w);
+    const char *const tb = reinterpret_cast<const char *>(L.tail);
+    const unsigned d0l = (unsigned)d0, d0h = (unsigned)(d0 >> 32);
+    constexpr unsigned kEmpty = 0xF7FFFFFFu;       // an empty slot: growth field 0 + 1, positions that read in range; its sum is forced to NaN
+    // sum bits of a key (all ones for an empty slot: a NaN, larger than every sum as an integer)
+    const auto sum_of = [&](unsigned code, bool valid) {
+        const float w0 = *reinterpret_cast<const float *>(wb + ((code & 255u) << 2));
+        const float w1 = *reinterpret_cast<const float *>(wb + (((code >> 8) & 255u) << 2));
+        const float w2 = *reinterpret_cast<const float *>(wb + (((code >> 16) & 255u) << 2));
+        const unsigned wt = (code >> 24) & 3u;
+        float rs = wt > 1u ? w0 + w1 : w0;
+        rs = wt > 2u ? rs + w2 : rs;
+        return valid ? __float_as_uint(rs) : 0xFFFFFFFFu;
+    };
+    const auto key_at = [&](int k, unsigned &code, unsigned &sb) {
+        const int i = k * 64 + lane;
+        code = i < n ? codes[i] : kEmpty;
+        sb = sum_of(code, i < n);
+    };
+    const auto parity = [&](const PbTep &t) {
+        u64 D = d0 ^ L.P[t.p0];
+        if (t.wt > 1) D ^= L.P[t.p1];
+        if (t.wt > 2) D ^= L.P[t.p2];
+        return D;
+    };
+    int sumf = 0, neg = 0, nsurv = 0;
+    unsigned fs = 0x7FFFFFFFu;     // the smallest sum on which rule 1 fires (against the chunk-start best)
+    unsigned short *const slist = reinterpret_cast<unsigned short *>(L.list);     // keys the cost bound could not rule out
+    const int nsl = (n + 63) >> 6;
+#pragma unroll 1
+    for (int k0 = 0; k0 < nsl; k0 += STEP) {       // (a rolled loop: unrolled over the 14 slices it is 12 KiB of code and the kernel spills)
+        unsigned code[STEP], sb[STEP];
+        uint2 r0[STEP], r1[STEP], r2[STEP];
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) {
+            key_at(k0 + u, code[u], sb[u]);
+            r0[u] = *reinterpret_cast<const uint2 *>(Pb + ((code[u] & 255u) << 3));
+            r1[u] = *reinterpret_cast<const uint2 *>(Pb + (((code[u] >> 8) & 255u) << 3));
+            r2[u] = *reinterpret_cast<const uint2 *>(Pb + (((code[u] >> 16) & 255u) << 3));
+        }
+        float t0[STEP], t1[STEP], t2[STEP], t3[STEP];
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) {
+            const unsigned lo = __builtin_amdgcn_bitop3_b32(r0[u].x, r1[u].x, r2[u].x, 0x96) ^ d0l;
+            const unsigned hi = __builtin_amdgcn_bitop3_b32(r0[u].y, r1[u].y, r2[u].y, 0x96) ^ d0h;
+            t0[u] = *reinterpret_cast<const float *>(tb + (__popc(lo & 0xFFFFu) << 2));
+            t1[u] = *reinterpret_cast<const float *>(tb + 68 + (__popc(lo >> 16) << 2));
+            t2[u] = *reinterpret_cast<const float *>(tb + 136 + (__popc(hi & 0xFFFFu) << 2));
+            t3[u] = *reinterpret_cast<const float *>(tb + 204 + (__popc(hi >> 16) << 2));
+        }
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) {
+            const float rs = __uint_as_float(sb[u]);
+            const bool surv = (((rs + t0[u]) + t1[u]) + (t2[u] + t3[u])) * 0.99999f < best0;      // (pbw_cost_floor)
+            const u64 sm = __ballot(surv);
+            if (sm) {
+                if (surv) slist[nsurv + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] = (unsigned short)((k0 + u) * 64 + lane);
+                nsurv += __popcll(sm);
+            }
+            const int fld = (int)((code[u] >> 26) & 3u);     // growth + 1
+            sumf += fld; neg += fld == 0;
+            const bool need = rs > r_safe;      // above the last safe probe (the last chunk of a search): the rule itself
+            if (__ballot(need)) {
+                float w1;
+                if (need && pb_not_promising(rs, best0, Fr, P.c4, L.cdfA, L.cdfH, w1) && sb[u] < fs) fs = sb[u];
+            }
+        }
+    }
+    const int negtot = wave_add_i32(neg), deltot = wave_add_i32(sumf) - 64 * STEP * ((nsl + STEP - 1) / STEP);     // (every slot looked at carried a + 1)
+    if (S.nlive - negtot <= 1) return -1;
+    // the survivors' exact costs, 64 at a time; those that beat the chunk-start best are the candidates (as 8-byte keys)
+    int ncand = 0;
+    if (nsurv) {
+        wave_fence();
+        for (int b0 = 0; b0 < nsurv && ncand <= 16; b0 += 64) {
+            const bool has = b0 + lane < nsurv;
+            const unsigned code = has ? codes[slist[b0 + lane]] : kEmpty;
+            const unsigned sbits = sum_of(code, has);
+            const float c = has ? pbw_cost_exact<CAP>(L, __uint_as_float(sbits), parity(pbw_tep(code))) : __builtin_inff();
+            const bool cand = c < best0;
+            const u64 cm = __ballot(cand);
+            if (cm) {
+                const int idx = ncand + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+                if (cand && idx < 16) { L.ck[idx] = ((u64)sbits << 32) | code; L.cc[idx] = c; }
+                ncand += __popcll(cm);
+            }
+        }
+        if (ncand > 16) return -1;
+    }
+    const auto sumbits = [](u64 key) { return (unsigned)(key >> 32); };
+    unsigned sF = (unsigned)wave_min_i32((int)fs);
+    if (ncand == 0) {
+        if (sF == 0x7FFFFFFFu) {     // no candidate, no key fires: the whole chunk is visited and nothing else happens
+            S.cmp += 2 * n; S.suc1 += n;
+            S.j += n; S.nlive += deltot;
+            return 0;
+        }
+        // no candidate, rule 1 fires: the search stops at the first key of the smallest firing sum (every key of that sum fires)
+        int cs = 0;
+        for (int k = 0; k < nsl; ++k) { unsigned code, sb; key_at(k, code, sb); cs += sb < sF; }
+        const int rank_stop = wave_add_i32(cs);
+        S.cmp += 2 * (rank_stop + 1);
+        S.suc1 += rank_stop;
+        stop = 1; ntep = S.j + rank_stop + 1;
+        return 1;
+    }
+    // ---- the candidates, in visit order; records and the success rule, sequentially (every lane the same arithmetic)
+    bool tie = false;
+    int nrec = 0, stop2 = 0;
+    wave_fence();
+    {
+        const u64 my = L.ck[lane & 15];
+        const float myc = L.cc[lane & 15];
+        int r = 0;
+        for (int d = 0; d < ncand; ++d) { const u64 o = L.ck[d]; r += sumbits(o) < sumbits(my); tie |= lane < ncand && sumbits(o) == sumbits(my) && o != my; }
+        wave_fence();
+        if (lane < ncand) { L.ck[r] = my; L.cc[r] = myc; }
+        wave_fence();
+    }
+    if (__ballot(tie)) return -1;
+    {
+        float before = best0;
+        for (int t = 0; t < ncand && !stop2; ++t) {
+            const u64 key = L.ck[t];
+            const float c = L.cc[t];
+            if (c < before) {
+                if (lane == 0) { L.rk[nrec] = key; L.rc[nrec] = c; }
+                ++nrec;
+                const float w1 = det_expf(P.c4 * __uint_as_float((unsigned)(key >> 32))) * Fr.spl;
+                if (pb_success_q(parity(pbw_tep((unsigned)key)), w1, L.qpar, Fr)) stop2 = 1;
+                before = c;
+            }
+        }
+    }
+    wave_fence();
+    // Rule 1 again for the keys from the first record on, each with the best it really sees (the record before it).  A lower
+    // best fires sooner, so a key that the LAST record's cost does not stop is stopped by none: probes with that cost leave
+    // the keys beyond the last safe probe to evaluate -- usually none.  Keys before the first record keep what the
+    // chunk-start best said (fs, if it lies before the first record).
+    if (nrec > 0) {
+        const unsigned s0 = sumbits(L.rk[0]);
+        float r_safe2;
+        {
+            const float rp = lane == 63 ? mx : mn + (mx - mn) * ((float)(lane + 1) * (1.0f / 64.0f));
+            float w1;
+            const float bs = pb_promising_bs(rp, L.rc[nrec - 1], Fr, P.c4, L.cdfA, L.cdfH, w1);
+            const u64 unsafe = ~__ballot((double)bs > Fr.p_t_pro * 1.001);
+            const int u = unsafe ? __builtin_ctzll(unsafe) : 64;
+            r_safe2 = u == 0 ? -1.0f : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rp), u - 1));
+        }
+        fs = fs < s0 ? fs : 0x7FFFFFFFu;
+        for (int k = 0; k < nsl; ++k) {
+            unsigned code, sb;
+            key_at(k, code, sb);
+            const u64 key = ((u64)sb << 32) | code;
+            const bool behind = sb != 0xFFFFFFFFu && sb >= s0;
+            int t = 0;
+            if (behind)
+                for (int u = 0; u < nrec; ++u) { const u64 r = L.rk[u]; t += sumbits(r) < sb; tie |= sumbits(r) == sb && r != key; }
+            const bool need = behind && __uint_as_float(sb) > r_safe2;
+            if (__ballot(need)) {
+                float w1;      // (the first record itself is judged with the chunk-start best: t = 0)
+                if (need && pb_not_promising(__uint_as_float(sb), t > 0 ? L.rc[t - 1] : best0, Fr, P.c4, L.cdfA, L.cdfH, w1) && sb < fs) fs = sb;
+            }
+        }
+        sF = (unsigned)wave_min_i32((int)fs);
+    }
+    // ---- the stop: the earlier of rule 1's first key and the record on which rule 2 fired
+    int reason = 0;
+    unsigned sstop = 0;
+    if (sF != 0x7FFFFFFFu) { reason = 1; sstop = sF; }
+    if (stop2) {
+        const unsigned sR = sumbits(L.rk[nrec - 1]);
+        if (reason == 1 && sR == sF) tie = true;
+        if (reason == 0 || sR < sF) { reason = 2; sstop = sR; }
+    }
+    int nbefore = nrec;           // records that really happened: those before the stop (and the stop itself for rule 2)
+    if (reason) {
+        nbefore = 0;
+        for (int u = 0; u < nrec; ++u) nbefore += sumbits(L.rk[u]) < sstop;
+        nbefore += reason == 2;
+    }
+    // positions: the keys below the last record that counts, the keys below the stopping sum; ties
+    const u64 bk = nbefore > 0 ? L.rk[nbefore - 1] : 0ull;
+    int cb = 0, cs = 0;
+    for (int k = 0; k < nsl; ++k) {
+        unsigned code, sb;
+        key_at(k, code, sb);
+        const u64 key = ((u64)sb << 32) | code;
+        if (nbefore > 0) { cb += sb < sumbits(bk); tie |= sb == sumbits(bk) && key != bk; }
+        if (reason == 1) cs += sb < sstop;
+    }
+    const int rank_best = wave_add_i32(cb), rank_stop = reason == 2 ? rank_best : wave_add_i32(cs);
+    if (__ballot(tie)) return -1;
+    // ---- commit
+    if (nbefore > 0) {
         const PbTep t = pbw_tep((unsigned)bk);
         u64 E = 1ull << t.p0;
         if (t.wt > 1) E |= 1ull << t.p1;
@@ -1436,6 +1706,66 @@ __device__ __forceinline__ int pbw_sorted_call(PbWaveLds<CAP> &L, const PbParams
     return L.sa.state;
 }
 
+// The sums (lo, T] once more with 8-byte keys: chunks of <= CAP keys, the sort-free pass with the keys in registers
+// (pbw_scan_chunk) and, where that cannot settle a chunk either, the sorted path.  For a chunk of 4-byte keys that pbw_scan4
+// gave up on (many improvement candidates, a tie against a reference key, a frontier that may shrink to one entry) and for the
+// workgroup kernel's fallback (coop_solo_range).  L.cur holds the cursors of the range's start; arguments and results in L.ra
+// (state 0 / 1 / 2 as in pb_wave_kernel).  A real function: its code (two more passes, the sort) stays out of the hot loop.
+template <int CAP>
+__device__ __noinline__ void pbw_redo_range(PbWaveLds<CAP> &L)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long pt[kPwSlots];
+    PbParams P;
+    P.order = L.ra.order; P.c4 = L.ra.c4;
+    const PbFrame Fr = L.ra.fr;
+    const u64 d0 = L.ra.d0;
+    const float Tcap = L.ra.T, smax = L.ra.smax;
+    const int target = L.ra.target;
+    float lo = L.ra.lo;
+    int done = L.ra.done;
+    const int end = done + L.ra.n;
+    const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);
+    PbwState S = L.ra.S;
+    int stop = L.ra.stop, ntep = L.ra.ntep;
+    wave_fence();
+    PbWalk W;
+    pbw_cursors_load<CAP>(L, W.ecur, lane);     // (the walk needs nothing but the cursors)
+    float tprev = 0.0f, nprev = 0.0f;
+    int state = 0;
+    while (state == 0 && done < end) {
+        float T;
+        int nwalks = 0;
+        const int n = pbw_next_chunk<CAP, false, 0>(L, W, P.order, lo, done, nall, target, lane, T, tprev, nprev, nwalks, pt, Tcap);
+        if (n <= 0) { state = 2; break; }
+        wave_fence();
+        const float cmn = lo < 0.0f ? L.w[63] : lo, cmx = T < __builtin_inff() ? T : smax;
+        state = pbw_scan_chunk<CAP>(L, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep);
+        if (state < 0) { state = pbw_sorted_call<CAP>(L, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep); pbw_cursors_load<CAP>(L, W.ecur, lane); }
+        lo = T;
+        done += n;
+    }
+    wave_fence();
+    if (lane == 0) { L.ra.S = S; L.ra.state = state; L.ra.stop = stop; L.ra.ntep = ntep; }
+    wave_fence();
+}
+// caller's side: park, call, take back (the caller has put the range's starting cursors into L.cur)
+template <int CAP>
+__device__ __forceinline__ int pbw_redo_call(PbWaveLds<CAP> &L, const PbParams &P, const PbFrame &Fr, u64 d0, float lo, float T, float smax, int done, int n,
+                                             int lane, PbwState &S, int &stop, int &ntep)
+{
+    wave_fence();
+    if (lane == 0) {
+        L.ra.S = S; L.ra.fr = Fr; L.ra.d0 = d0; L.ra.lo = lo; L.ra.T = T; L.ra.smax = smax; L.ra.c4 = P.c4; L.ra.done = done; L.ra.n = n;
+        L.ra.order = P.order; L.ra.target = CAP * 13 / 16; L.ra.stop = stop; L.ra.ntep = ntep;
+    }
+    wave_fence();
+    pbw_redo_range<CAP>(L);
+    wave_fence();
+    S = L.ra.S; stop = L.ra.stop; ntep = L.ra.ntep;
+    return L.ra.state;
+}
+
 // A long search handed from the chunk kernel to the workgroup kernel: ONE record per frame with everything the search needs,
 // so that the receiving workgroup starts after a single wide load (its 1024 threads copy the record into LDS side by side)
 // instead of the chain frame number -> source index -> permutation -> y that the chunk kernel went through:
@@ -1558,25 +1888,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
         PBW_STAMP(kPwSetup);
         const float smax = P.order > 2 ? (L.w[0] + L.w[1]) + L.w[2] : (P.order > 1 ? L.w[0] + L.w[1] : L.w[0]);
         int stop = 0, ntep = P.nmax, state = 0;   // state: 0 = searching, 1 = a rule fired, 2 = to the list replay, 3 = to the workgroup kernel
-        bool asked = false;
+        bool asked = false, firstc = true;       // (firstc: the frame's first chunk here -- its size is tuned apart, many searches end in it)
         float tprev = 0.0f, nprev = 0.0f;
         while (state == 0 && done < nall) {
             float T;
             int nwalks = 0;
-            const int n = pbw_next_chunk<CAP, PROF, ROT>(L, W, P.order, lo, done, nall, done == 0 ? P.t1 : P.t2, lane, T, tprev, nprev, nwalks, pt);
+            // a chunk of 4-byte keys (up to 2 CAP + 64 of them); W.ecur keeps the cursors it started from until it is judged
+            const int n = pbw_next_chunk<CAP, PROF, ROT, true, false>(L, W, P.order, lo, done, nall, firstc ? P.t1 : P.t2, lane, T, tprev, nprev, nwalks, pt);
+            firstc = false;
             PBW_STAMP(kPwWalk);
             if constexpr (PROF) { pt[kPwChunks] += 1; pt[kPwWalks] += nwalks; pt[kPwKeys] += n > 0 ? n : 0; }
             if (n < 0) { state = 2; break; }
             if (n == 0) break;
             wave_fence();
             const float cmn = lo < 0.0f ? L.w[63] : lo, cmx = T < __builtin_inff() ? T : smax;
-            state = pbw_scan_chunk<CAP>(L, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep);
+            state = pbw_scan4<CAP>(L, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep);
             PBW_STAMP(kPwScan);
-            if (state < 0) {
+            if (state < 0) {     // not settled without a sort: the same sums once more, in chunks of 8-byte keys (a function call)
                 if constexpr (PROF) pt[kPwSorted] += 1;
-                state = pbw_sorted_call<CAP>(L, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep);
-                pbw_cursors_load<CAP>(L, W.ecur, lane);        // (not kept across the call: L.cur holds the committed cursors)
+                pbw_cursors_store<CAP>(L, W.ecur, lane);
+                state = pbw_redo_call<CAP>(L, P, Fr, d0, lo, T, smax, done, n, lane, S, stop, ntep);
             }
+            pbw_cursors_load<CAP>(L, W.ecur, lane);          // commit (L.cur: the cursors behind the chunk, whoever walked it)
             lo = T;
             done += n;
             if (state == 0 && done >= budget && !asked && done < nall && len < P.handoff_maxlen) {
@@ -2156,38 +2489,15 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
 // the range's start (all 32 rows); arguments in L.su / L.bs / L.sP, results in L.bs / L.bstate / L.bstop / L.bntep
 // (state 0 / 1 / 2 as in pb_wave_kernel).
 template <int NW>
-__device__ __noinline__ void coop_solo_range(PbCoopLds<NW> &L)
+__device__ __forceinline__ void coop_solo_range(PbCoopLds<NW> &L)
 {
     constexpr int CAP = kPbWaveCap;
     const int lane = threadIdx.x & 63;
-    unsigned long long pt[kPwSlots];
-    const PbParams P = L.sP;
-    const PbFrame Fr = L.su.fr;
-    const u64 d0 = L.su.d0;
-    const float Tcap = L.su.T, smax = L.su.smax;
-    float lo = L.su.lo;
-    int done = L.su.done;
-    const int end = done + L.su.n;
-    const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);
     PbwState S = L.bs;
     int stop = L.bstop, ntep = L.bntep;
-    wave_fence();
-    PbWalk W;
-    pbw_cursors_load<CAP>(L.one, W.ecur, lane);     // (the walk needs nothing but the cursors)
-    float tprev = 0.0f, nprev = 0.0f;
-    int state = 0;
-    while (state == 0 && done < end) {
-        float T;
-        int nwalks = 0;
-        const int n = pbw_next_chunk<CAP, false, 0>(L.one, W, P.order, lo, done, nall, P.t2, lane, T, tprev, nprev, nwalks, pt, Tcap);
-        if (n <= 0) { state = 2; break; }
-        wave_fence();
-        const float cmn = lo < 0.0f ? L.one.w[63] : lo, cmx = T < __builtin_inff() ? T : smax;
-        state = pbw_scan_chunk<CAP>(L.one, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep);
-        if (state < 0) { state = pbw_sorted_call<CAP>(L.one, P, Fr, d0, n, cmn, cmx, lane, S, stop, ntep); pbw_cursors_load<CAP>(L.one, W.ecur, lane); }
-        lo = T;
-        done += n;
-    }
+    PbParams P;
+    P.order = L.sP.order; P.c4 = L.sP.c4;
+    const int state = pbw_redo_call<CAP>(L.one, P, L.su.fr, L.su.d0, L.su.lo, L.su.T, L.su.smax, L.su.done, L.su.n, lane, S, stop, ntep);
     wave_fence();
     if (lane == 0) { L.bs = S; L.bstate = state; L.bstop = stop; L.bntep = ntep; }
 }
@@ -2530,7 +2840,7 @@ ldpc_pb_tuning pb_default_tuning()
 {
     ldpc_pb_tuning t;
     t.budget = 4096; t.budget_s = t.budget / 8; t.budget_m = t.budget / 4; t.budget_l = 2 * t.budget; t.budget_xl = 6 * t.budget;
-    t.t1 = 320; t.t2 = kPbWaveCap * 13 / 16; t.t3 = 3072;
+    t.t1 = 320; t.t2 = 600; t.t3 = 3072;        // (t2 measured at 1.0 / 2.5 dB: 512: 4.16 / 0.548 ms, 600: 4.08 / 0.532, 676: 4.11 / 0.554, 760: 4.37 / 0.561)
     t.late_min = 4608; t.late_maxlen = 4400; t.late_pct = 1000; t.late_div = 4;
     t.handoff_maxlen = 1 << 30;
     return t;
@@ -2749,8 +3059,9 @@ int ldpc_ctx_set_pb_tuning(ldpc_ctx *ctx, const ldpc_pb_tuning *t)
     const int budgets[5] = {v.budget_s, v.budget_m, v.budget, v.budget_l, v.budget_xl};
     for (int b : budgets)
         if (b < 1) return fail(LDPC_E_ARG, "ldpc_ctx_set_pb_tuning: hand-over budgets must be >= 1 TEP (got %d)", b);
-    if (v.t1 < 32 || v.t1 > kPbWaveCap || v.t2 < 32 || v.t2 > kPbWaveCap)
-        return fail(LDPC_E_ARG, "ldpc_ctx_set_pb_tuning: chunk targets t1 / t2 must lie in [32, %d] (got %d, %d)", kPbWaveCap, v.t1, v.t2);
+    constexpr int kcap = PbwCaps<kPbWaveCap, true>::KCAP;
+    if (v.t1 < 32 || v.t1 > kcap || v.t2 < 32 || v.t2 > kcap)
+        return fail(LDPC_E_ARG, "ldpc_ctx_set_pb_tuning: chunk targets t1 / t2 must lie in [32, %d] (got %d, %d)", kcap, v.t1, v.t2);
     if (v.t3 < 256 || v.t3 > kCoopCap) return fail(LDPC_E_ARG, "ldpc_ctx_set_pb_tuning: t3 must lie in [256, %d] (got %d)", kCoopCap, v.t3);
     if (v.late_div < 1 || v.late_pct < 0 || v.late_min < 0 || v.late_maxlen < 0 || v.handoff_maxlen < 0)
         return fail(LDPC_E_ARG, "ldpc_ctx_set_pb_tuning: late_div must be >= 1 and the other fields >= 0");

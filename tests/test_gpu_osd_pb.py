@@ -136,7 +136,7 @@ def test_pb_tuning_is_validated(dec):
     """Bad values are refused and change nothing (LDPC_PB_LATE_DIV=0 used to reach the kernel); no field = defaults."""
     from short_ldpc_decoding_osd_amd import _lib
     before = dec.pb_tuning()
-    for bad in (dict(late_div=0), dict(budget=0), dict(t2=513), dict(t1=8), dict(t3=5000), dict(budget_xl=-1)):
+    for bad in (dict(late_div=0), dict(budget=0), dict(t2=833), dict(t1=8), dict(t3=5000), dict(budget_xl=-1)):
         with pytest.raises(_lib.LdpcError):
             dec.set_pb_tuning(**bad)
         assert dec.pb_tuning() == before
@@ -145,7 +145,7 @@ def test_pb_tuning_is_validated(dec):
     dec.set_pb_tuning(t2=256, late_pct=65, late_div=2)
     assert dec.pb_tuning()["t2"] == 256
     dec.set_pb_tuning()
-    assert dec.pb_tuning() == before == dict(budget=4096, budget_s=512, budget_m=1024, budget_l=8192, budget_xl=24576, t1=320, t2=312,
+    assert dec.pb_tuning() == before == dict(budget=4096, budget_s=512, budget_m=1024, budget_l=8192, budget_xl=24576, t1=320, t2=600,
                                              t3=3072, late_min=4608, late_maxlen=4400, late_pct=1000, late_div=4, handoff_maxlen=1 << 30)
 
 
