@@ -208,7 +208,10 @@ typedef struct ldpc_osd_params {
                             stop reason 0 = none / 1 = promising rule (:129) / 2 = success rule (:145)} */
     int64_t y_frames;    /* 0 = d_index is trusted (default).  > 0 = debug bound: the number of frames d_y holds;
                             ldpc_osd_decode / ldpc_osd_search then run on a sanitised copy of d_index (entries outside
-                            [0, y_frames) replaced by 0) and count the offenders, see ldpc_osd_index_errors           */
+                            [0, y_frames) replaced by 0) and count the offenders, see ldpc_osd_index_errors.
+                            It guards CALLER-MADE lists: ldpc_pipeline_run writes d_index itself (its compaction emits
+                            valid, ascending frame numbers only), so there the field checks nothing that can be wrong, and
+                            the pipeline's counting launch reads the list the library wrote              */
 } ldpc_osd_params;
 
 /* PB-OSD tuning of a context (ABI 4; rounds 1-3 read these from LDPC_PB_* environment variables on every call).
