@@ -660,7 +660,9 @@ int orc_pb_osd(const int32_t *G, const float *y, const uint8_t *label, int order
             for (int p = 0; p < 64; ++p) prod = prod * (((D >> p) & 1) ? 2.0f * q[64 + p] : 2.0f * (1.0f - q[64 + p]));
             const float p_suc = 1.0f / (1.0f + ratio / prod);
             ++suc2;
-            if ((double)p_suc > p_t_suc) { stop = 2; ntep = (int)j + 1; break; }
+            /* pb_testing.py:145 `p_e_suc > p_t_suc`: a float32 tensor against a NumPy double -- TensorFlow converts the double TO
+               float32 and compares there (rounds 1-3 compared in float64: a 1-ulp window) */
+            if (p_suc > (float)p_t_suc) { stop = 2; ntep = (int)j + 1; break; }
         }
     }
     free(fr);

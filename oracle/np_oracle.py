@@ -566,7 +566,7 @@ def pb_osd_frame(yp, labelp, Gp, order, snr_db):
             for i in range(k, n):
                 prod = F32(prod * (F32(2) * q[i] if disc[i] else F32(2) * (F32(1) - q[i])))
             p_suc = F32(F32(1) / F32(F32(1) + F32(ratio / prod)))
-            if float(p_suc) > p_t_suc:
+            if p_suc > F32(p_t_suc):                                    # (:145: TF compares the f32 tensor with the double cast TO f32)
                 stop, num_teps = 2, j + 1
                 break
     fail = None if labelp is None else bool(np.any(best_cw != np.asarray(labelp)))

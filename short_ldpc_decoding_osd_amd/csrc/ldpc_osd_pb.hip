@@ -5,7 +5,8 @@
 // order", pop, append <= 2 children) with two probabilistic stopping rules (acquire_prob_promising :448-461,
 // acquire_p_e_suc :423-436, thresholds :485-500).  All probabilities follow the float conventions of
 // oracle/ldpc_oracle.c orc_pb_osd: float32 with det_expf (IEEE + - * / only, host and device agree bit for
-// bit), float64 binomial-CDF recurrences, threshold comparisons in float64.
+// bit), float64 binomial-CDF recurrences; the promising rule compares in float64 (both sides are float64 tensors in the
+// reference, :129), the success rule in float32 (:145: a float32 tensor against a NumPy double, which TensorFlow casts down).
 //
 // The list is NOT replayed TEP by TEP (the round-1 kernel did that: one wavefront, ~1.2 us per TEP, 51 ms for
 // the rare frame on which no rule fires).  Three facts make the search batch-parallel and still exact
@@ -243,7 +244,7 @@ __device__ __forceinline__ bool pb_success_q(u64 D, float w1, const float *qpar,
         prod = prod * (((D >> p) & 1) ? 2.0f * qp : 2.0f * (1.0f - qp));
     }
     const float p_suc = 1.0f / (1.0f + ratio / prod);
-    return (double)p_suc > F.p_t_suc;
+    return p_suc > (float)F.p_t_suc;      // (pb_testing.py:145: TensorFlow compares the float32 tensor with the double cast TO float32)
 }
 
 __device__ __forceinline__ bool pb_success(u64 D, float w1, const float2 *tq, const PbFrame &F)
@@ -256,7 +257,7 @@ __device__ __forceinline__ bool pb_success(u64 D, float w1, const float2 *tq, co
         prod = prod * (((D >> p) & 1) ? t.y : t.x);
     }
     const float p_suc = 1.0f / (1.0f + ratio / prod);
-    return (double)p_suc > F.p_t_suc;
+    return p_suc > (float)F.p_t_suc;      // (pb_testing.py:145: TensorFlow compares the float32 tensor with the double cast TO float32)
 }
 
 // number of TEPs of weight 1, 1..2, 1..3 over 64 positions
@@ -2818,7 +2819,7 @@ __global__ __launch_bounds__(256) void pb_seq_kernel(const float *__restrict__ y
                 }
                 const float p_suc = 1.0f / (1.0f + ratio / prod);
                 ++suc2;
-                if ((double)p_suc > p_t_suc) { stop = 2; ntep = j + 1; break; }
+                if (p_suc > (float)p_t_suc) { stop = 2; ntep = j + 1; break; }
             }
         }
         pb_write(L, S, O, f, lane, bestE, bestD, best, bestidx, ntep, cmp, suc1, suc2, stop);

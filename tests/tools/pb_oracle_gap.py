@@ -111,7 +111,7 @@ def literal_pb(yp, Gp, order, snr_db, cap):
             for i in range(k, n):
                 prod = F32(prod * (F32(2) * q[i] if disc[i] else F32(2) * (F32(1) - q[i])))
             p_suc = F32(F32(1) / F32(F32(1) + F32(ratio / prod)))
-            if float(p_suc) > p_t_suc:
+            if p_suc > F32(p_t_suc):
                 stop, num_teps = 2, j + 1
                 break
     return dict(codeword=best_cw, metric=w_dmin, num_teps=num_teps, best_index=best_index,
