@@ -156,10 +156,19 @@ int ldpc_pipeline_run(ldpc_ctx *ctx, const ldpc_pipeline *p, void *stream)
             if (counted && !fused &&
                 (rc = ldpc_osd_counts(ctx, p->d_cw, p->d_label_bits, p->d_index, p->d_count, p->d_ntep, p->B, p->d_osd_counts, stream))) return rc;
             return LDPC_OK;
-        } else {                          // ldpc_osd_decode on the context's workspace
+        } else {                          // ldpc_osd_decode: one fused kernel (conventional order 2) or the stream's workspace
             LDPC_EV(3);
-            if ((rc = ldpc_osd_decode(ctx, p->d_llr, p->d_index, p->d_count, p->B, &p->osd, p->d_cw, p->d_metric, p->d_best,
-                                      p->d_ntep, stream))) return rc;
+            if (!ctx->osd_ok) return fail(LDPC_E_UNSUPPORTED, "OSD kernels need an (n=128, k=64) code; this one is (%d,%d)", ctx->code.n, ctx->code.k);
+            if (p->osd.order < 0 || p->osd.order > 3 || p->osd.algo < 0 || p->osd.algo > 2 || (p->osd.algo == LDPC_OSD_PB && p->osd.order < 1))
+                return fail(LDPC_E_ARG, "ldpc_pipeline_run: OSD order %d / algorithm %d", p->osd.order, p->osd.algo);
+            const bool counted = p->d_label_bits && p->d_osd_counts;
+            bool fused = false;
+            if (p->B > 0 && (rc = osd_decode_counted(ctx, p->d_llr, p->d_index, p->d_count, p->B, &p->osd, p->d_cw, p->d_metric, p->d_best,
+                                                     p->d_ntep, counted ? p->d_label_bits : nullptr, counted ? p->d_osd_counts : nullptr, s, &fused))) return rc;
+            LDPC_EV(4);
+            if (counted && !fused &&
+                (rc = ldpc_osd_counts(ctx, p->d_cw, p->d_label_bits, p->d_index, p->d_count, p->d_ntep, p->B, p->d_osd_counts, stream))) return rc;
+            return LDPC_OK;
         }
         LDPC_EV(4);
         if (p->d_label_bits && p->d_osd_counts &&

@@ -84,6 +84,9 @@ int osd_search_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, 
                        const uint8_t *d_perm, const uint64_t *d_parity, const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric,
                        int32_t *d_best, int32_t *d_ntep, const uint64_t *d_label, int64_t *d_counts, hipStream_t s,
                        bool *counted_by_search = nullptr);
+int osd_decode_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                       const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric, int32_t *d_best, int32_t *d_ntep,
+                       const uint64_t *d_label, int64_t *d_counts, hipStream_t s, bool *counted_by_search);
 int eval_and_compact(ldpc_ctx *ctx, const uint64_t *d_hard, const uint64_t *d_label, const uint8_t *d_fail, int64_t B,
                      int64_t *d_counts, int32_t *d_index, int32_t *d_count, hipStream_t st);
 

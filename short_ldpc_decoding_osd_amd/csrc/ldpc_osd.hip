@@ -82,12 +82,11 @@ struct FrontResult {
 
 
 // sort + column gather + elimination + bookkeeping of one frame (one wavefront); results in registers
-__device__ __forceinline__ FrontResult front_device(FrontLds &L, const float *__restrict__ y, long long src,
-                                                    const u64 *__restrict__ Gcols, int lane)
+// (a1 / a2: the magnitude bits of y[lane] / y[64 + lane])
+__device__ __forceinline__ FrontResult front_device_vals(FrontLds &L, unsigned a1, unsigned a2, const u64 *__restrict__ Gcols, int lane)
 {
     // ---- reliability sort: rank of each |y| in descending order, ties -> lower index ------
     // sort key = (|y| bits, 127 - index) as one 64-bit integer: "u before v" <=> key_u > key_v (bucket_ranks)
-    const unsigned a1 = __float_as_uint(y[src * 128 + lane]) & 0x7FFFFFFFu, a2 = __float_as_uint(y[src * 128 + 64 + lane]) & 0x7FFFFFFFu;
     const float bs = bucket_scale(a1, a2);
     int r1, r2;
     bucket_ranks(L.rank, ((u64)a1 << 32) | (unsigned)(127 - lane), ((u64)a2 << 32) | (unsigned)(63 - lane), bucket_of(a1, bs),
@@ -125,6 +124,12 @@ __device__ __forceinline__ FrontResult front_device(FrontLds &L, const float *__
     res.ns = ns;
     wave_fence();
     return res;
+}
+
+__device__ __forceinline__ FrontResult front_device(FrontLds &L, const float *__restrict__ y, long long src,
+                                                    const u64 *__restrict__ Gcols, int lane)
+{
+    return front_device_vals(L, __float_as_uint(y[src * 128 + lane]) & 0x7FFFFFFFu, __float_as_uint(y[src * 128 + 64 + lane]) & 0x7FFFFFFFu, Gcols, lane);
 }
 
 __global__ __launch_bounds__(64) void osd_front_kernel(const float *__restrict__ y, const int *__restrict__ index,
@@ -523,6 +528,86 @@ __global__ __launch_bounds__(64) void osd_search2r_kernel(const float *__restric
         f0 = f1; f1 = f2; f2 += G;
         o1a = o1b; o2a = o2b; Pa = Pb; srca = srcb; y1a = y1b; y2a = y2b; laba = labb;
         o1b = o1c; o2b = o2c; Pb = Pc; srcb = srcc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// ldpc_osd_decode / ldpc_pipeline_run for the conventional order-2 OSD when the caller does not ask for the front-end
+// results: front end AND scan of a frame in ONE wavefront, back to back -- the permutation, the rows of P' and the primed
+// channel values pass from one to the other in registers and LDS and never touch memory.  Two launches moved 640 B of
+// workspace per frame out and in again and read y twice (PMC, round 3: 41 + 49 MB per 33.5 k frames against 18 MB
+// algorithmic: 5.1x); this form reads 512 B and writes 24 B per frame.  The front end's 3.6 KiB of LDS lie inside the
+// scan's LUT area (built afterwards), the frame's y row in its survivor ring (filled afterwards): 10 KiB, 16 wavefronts per CU.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void osd_fused2r_kernel(const float *__restrict__ y, const int *__restrict__ index,
+                                                         const int *__restrict__ count, long long F,
+                                                         const u64 *__restrict__ Gcols, int dir, const int *__restrict__ base2,
+                                                         u64 *__restrict__ cw_out, float *__restrict__ metric_out,
+                                                         int *__restrict__ best_out, int *__restrict__ ntep_out,
+                                                         const u64 *__restrict__ label, u64 *__restrict__ counts)
+{
+    __shared__ Search2rLds LL;
+    static_assert(sizeof(FrontLds) <= sizeof(LL.lut), "the front end works inside the LUT area");
+    FrontLds &LF = *reinterpret_cast<FrontLds *>(LL.lut);
+    float *const yrow = reinterpret_cast<float *>(LL.q) + 256;      // bytes 1024 .. 1535 of the ring (wpar: 0 .. 255, cw: 512 .. 527)
+    const int lane = threadIdx.x;
+    long long nframes = F;
+    if (count) { const long long c = *count; nframes = c < F ? c : F; }
+    if (counts && blockIdx.x == 0 && lane == 0) { atomicAdd(&counts[0], (u64)nframes); atomicAdd(&counts[2], (u64)nframes * 2081ull); }
+    // software pipeline over the frames of this workgroup: the frame number two frames ahead, the y row one frame ahead
+    const long long G = gridDim.x;
+    long long f0 = blockIdx.x, f1 = f0 + G, f2 = f1 + G;
+    long long srca = 0, srcb = 0;
+    float ya1 = 0.0f, ya2 = 0.0f;
+    u64 laba = 0;
+    if (f0 < nframes) srca = index ? index[f0] : f0;
+    if (f1 < nframes) srcb = index ? index[f1] : f1;
+    if (f0 < nframes) { ya1 = y[srca * 128 + lane]; ya2 = y[srca * 128 + 64 + lane]; if (label && lane < 2) laba = label[srca * 2 + lane]; }
+    while (f0 < nframes) {
+        float yb1 = 0.0f, yb2 = 0.0f;
+        u64 labb = 0;
+        if (f1 < nframes) { yb1 = y[srcb * 128 + lane]; yb2 = y[srcb * 128 + 64 + lane]; if (label && lane < 2) labb = label[srcb * 2 + lane]; }
+        long long srcc = 0;
+        if (f2 < nframes) srcc = index ? index[f2] : f2;
+        // ---- frame f0: front end
+        yrow[lane] = ya1; yrow[64 + lane] = ya2;
+        const FrontResult fr = front_device_vals(LF, __float_as_uint(ya1) & 0x7FFFFFFFu, __float_as_uint(ya2) & 0x7FFFFFFFu, Gcols, lane);
+        const float y1 = yrow[fr.o1], y2 = yrow[fr.o2];            // y'[p] = y[perm[p]]
+        wave_fence();
+        // ---- scan (the frame body of osd_search2r_kernel)
+        SearchFrame S;
+        S.o1 = fr.o1; S.o2 = fr.o2;
+        const u64 Pa = fr.Prow;
+        const float w1 = __builtin_fabsf(y1), w2 = __builtin_fabsf(y2);
+        LL.wpar()[lane] = w2;
+        S.hm = __ballot(!(y1 > 0.0f));
+        S.hp = __ballot(!(y2 > 0.0f));
+        wave_fence();
+        build_byte_luts<8>(LL.lut, LL.wpar(), lane);
+        S.d0 = wave_xor64(((S.hm >> lane) & 1) ? Pa : 0ull) ^ S.hp;
+        wave_fence();
+        float best; int bestt; u64 bestD, bestE;
+        search2r_device(LL, S, Pa, w1, dir, base2, lane, best, bestt, bestD, bestE);
+        {
+            const u64 mrb_bits = S.hm ^ bestE, par_bits = bestD ^ S.hp;
+            u64 *const cw = LL.cw();
+            if (lane < 2) cw[lane] = 0;
+            wave_fence();
+            if ((mrb_bits >> lane) & 1) atomicOr(&cw[S.o1 >> 6], 1ull << (S.o1 & 63));
+            if ((par_bits >> lane) & 1) atomicOr(&cw[S.o2 >> 6], 1ull << (S.o2 & 63));
+            wave_fence();
+            const u64 word = lane < 2 ? cw[lane] : 0ull;
+            if (lane < 2) cw_out[f0 * 2 + lane] = word;
+            if (counts && __ballot(lane < 2 && word != laba) && lane == 0) atomicAdd(&counts[1], 1ull);
+            wave_fence();
+        }
+        if (lane == 0) {
+            if (metric_out) metric_out[f0] = best;
+            if (best_out) best_out[f0] = bestt;
+            if (ntep_out) ntep_out[f0] = 2081;
+        }
+        f0 = f1; f1 = f2; f2 += G;
+        srca = srcb; srcb = srcc; ya1 = yb1; ya2 = yb2; laba = labb;
     }
 }
 
@@ -992,6 +1077,34 @@ static int launch_search(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index
 }  // extern "C"
 
 namespace ldpc {
+// ldpc_osd_decode (+ ldpc_osd_counts where the kernel can count itself: *counted_by_search).  The conventional order-2 OSD runs
+// front end and scan in ONE kernel with no workspace (osd_fused2r_kernel); everything else the front end into the stream's
+// workspace, then the search.  (params->reserved bits 0 / 3, the cross-check scans, keep the two-kernel route.)
+int osd_decode_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
+                       const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric, int32_t *d_best, int32_t *d_ntep,
+                       const uint64_t *d_label, int64_t *d_counts, hipStream_t s, bool *counted_by_search)
+{
+    if (counted_by_search) *counted_by_search = false;
+    int rc;
+    if ((rc = guarded_index(ctx, p, d_index, d_count, F, s, &d_index))) return rc;
+    if (p->algo == LDPC_OSD_CONVENTIONAL && p->order == 2 && !(p->reserved & 9) && ctx->dpp_wave_rol_dir != 0) {
+        const long long grid = (long long)ctx->cu_count * 16 * 6;      // (as the scan alone: 6x the resident wavefronts)
+        const bool cnt = d_label && d_counts;
+        hipLaunchKernelGGL(osd_fused2r_kernel, dim3((unsigned)(F < grid ? F : grid)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
+                           reinterpret_cast<const u64 *>(ctx->d_Gcols), ctx->dpp_wave_rol_dir, state(ctx)->d_base2,
+                           reinterpret_cast<u64 *>(d_cw), d_metric, d_best, d_ntep, cnt ? reinterpret_cast<const u64 *>(d_label) : nullptr,
+                           cnt ? reinterpret_cast<u64 *>(d_counts) : nullptr);
+        LDPC_HIP(hipGetLastError());
+        if (counted_by_search) *counted_by_search = cnt;
+        return LDPC_OK;
+    }
+    StreamWs *w;
+    if ((rc = stream_ws(ctx, s, F, &w))) return rc;
+    hipLaunchKernelGGL(osd_front_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
+                       reinterpret_cast<const u64 *>(ctx->d_Gcols), w->d_perm, w->d_parity, (int *)nullptr);
+    return launch_search(ctx, d_y, d_index, d_count, F, w->d_perm, w->d_parity, p, d_cw, d_metric, d_best, d_ntep, s);
+}
+
 // ldpc_osd_search + ldpc_osd_counts for ldpc_pipeline_run: one launch where the search kernel can count itself
 int osd_search_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int32_t *d_count, int64_t F,
                        const uint8_t *d_perm, const uint64_t *d_parity, const ldpc_osd_params *p, uint64_t *d_cw, float *d_metric,
@@ -1037,13 +1150,7 @@ int ldpc_osd_decode(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, con
     int rc = check_params(ctx, p, "ldpc_osd_decode");
     if (rc) return rc;
     if (F == 0) return LDPC_OK;
-    hipStream_t s = (hipStream_t)stream;
-    StreamWs *w;
-    if ((rc = stream_ws(ctx, s, F, &w))) return rc;
-    if ((rc = guarded_index(ctx, p, d_index, d_count, F, s, &d_index))) return rc;
-    hipLaunchKernelGGL(osd_front_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,
-                       reinterpret_cast<const u64 *>(ctx->d_Gcols), w->d_perm, w->d_parity, (int *)nullptr);
-    return launch_search(ctx, d_y, d_index, d_count, F, w->d_perm, w->d_parity, p, d_cw, d_metric, d_best, d_ntep, s);
+    return osd_decode_counted(ctx, d_y, d_index, d_count, F, p, d_cw, d_metric, d_best, d_ntep, nullptr, nullptr, (hipStream_t)stream, nullptr);
 }
 
 int ldpc_osd_index_errors(ldpc_ctx *ctx, int64_t *count)
