@@ -1,11 +1,12 @@
 #!/bin/bash
 # profiles/rNN evidence for EVERY bench workload: kernel trace (--stats) + the four PMC passes each (separate runs, --kernel-trace
-# only beside --pmc), folded into profiles/<round>/kernel_stats_<workload>_<round>.csv and pmc_counters_<workload>_<round>.json.
+# only beside --pmc), folded into gpurun_out/<round>/kernel_stats_<workload>_<round>.csv and pmc_counters_<workload>_<round>.json
+# (copied into profiles/<round>/ once they are back from the GPU box).
 #   scripts/profile_all.sh <round, e.g. r04> [workload names ...]          (run on the GPU box; default: all)
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; B=$R/bench.py; O=$R/gpurun_out; RND=${1:-r04}; shift || true
-P=$R/profiles/$RND; mkdir -p $P $O
+P=$O/$RND; mkdir -p $P $O     # (only gpurun_out/ travels back from the GPU box: copy gpurun_out/<round>/* into profiles/<round>/ afterwards)
 cd /tmp
 run() {   # name, frames per launch, bench args...
   local name=$1 frames=$2; shift 2

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the bench / sweep lines a round's profiles/rNN quotes.  usage: scripts/round_measurements.sh <round, e.g. r04>   (GPU box)
-RND=${1:-r04}; O=gpurun_out; P=profiles/$RND; mkdir -p $O $P
+RND=${1:-r04}; O=gpurun_out; P=$O/$RND; mkdir -p $O $P     # (copy gpurun_out/<round>/* into profiles/<round>/ afterwards)
 b() { local name=$1; shift; timeout -k 10 400 python bench.py "$@" > $O/${RND}_$name.json 2> $O/${RND}_$name.err; local rc=$?; echo "[$name] rc=$rc"; [ $rc -eq 0 ] && cp $O/${RND}_$name.json $P/bench_${name}_${RND}.json; }
 b driver --gpus 1 --steps 20 --warmup 5
 b default
