@@ -149,6 +149,22 @@ def test_pb_tuning_is_validated(dec):
                                              t3=3072, late_min=4608, late_maxlen=4400, late_pct=1000, late_div=4, handoff_maxlen=1 << 30)
 
 
+@pytest.mark.parametrize("tuning", [dict(t1=32, t2=32), dict(t1=832, t2=832), dict(t1=64, t2=800, budget_s=100000, budget_m=100000, budget=100000),
+                                    dict(t1=500, t2=97, budget_s=300, budget_m=300, budget=300, t3=256)])
+def test_pb_results_do_not_depend_on_the_tuning(dec, tuning):
+    """Chunk targets at both ends of their range (tiny chunks; chunks that overflow the 832-key buffer and the work-list ring and
+    are retried; a chunk extended in place), with and without hand-over to the workgroup kernel: counts, stops, winners and
+    metrics stay exact (the bounds of a chunk are free parameters of the method)."""
+    prev = dec.set_pb_tuning(**tuning)
+    try:
+        y, cw = _failures(dec, 1.5, 900, seed=21)
+        _check(dec, y[:400], cw[:400], 3, 1.5, None)
+        y2, cw2 = _failures(dec, 2.5, 1200, seed=22)
+        _check(dec, y2[:200], cw2[:200], 2, 2.5, None)
+    finally:
+        dec.set_pb_tuning(**prev)
+
+
 @pytest.mark.parametrize("quant", [1024.0, 16384.0])
 def test_pb_workgroup_kernel_ties(dec, quant):
     """Long searches on finely quantised channel values: equal sums deep inside a search, where the workgroup kernel's
