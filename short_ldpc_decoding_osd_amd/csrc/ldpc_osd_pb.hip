@@ -22,12 +22,15 @@
 //
 //   pb_singles_kernel  one frame per wavefront: the pop sequence starts with the weight-1 TEPs {63}, {62}, ...
 //                      while |y'_p| < |y'_62| + |y'_63| (the smallest weight-2 sum); one TEP per lane.  Two thirds
-//                      of the frames stop here at 2.5 dB; the others are appended to list A.
+//                      of the frames stop here at 2.5 dB; the others are appended to list A, each with ONE 1536-byte record
+//                      that holds everything its search needs (round 4).
 //   pb_wave_kernel     one frame of list A per WAVEFRONT (round 3; rounds 1-2 used 256- and 1024-thread workgroups),
-//                      continued from the head: chunks of <= 512 TEPs, each = the members of a sum range walked directly
-//                      from the sorted reliabilities, judged by a sort-free pass (sorted only when that cannot settle the
-//                      chunk).  No workgroup barrier anywhere.  Massive ties go to list B; a search that passes a budget
-//                      of TEPs (chosen on the device from the number of searching frames) leaves with its state.
+//                      continued from the head: chunks of <= 832 TEPs (4-byte keys, round 4), each = the members of a sum
+//                      range walked directly from the sorted reliabilities, judged by a sort-free pass (pbw_scan4); what that
+//                      cannot settle is redone over the same sum range with 8-byte keys, chunks of <= 384, and sorted if need
+//                      be (pbw_redo_range, a real function).  No workgroup barrier anywhere.  Massive ties go to list B; a
+//                      search that passes a budget of TEPs (chosen on the device from the number of searching frames) leaves
+//                      with its state.  120 VGPRs, 10 KiB of LDS: four wavefronts per SIMD.
 //   pb_coop_kernel     those long searches, one frame per 16-wavefront WORKGROUP: chunks of <= 4096 TEPs counted by
 //                      bisection and generated once, every wavefront judging the keys it generated; one workgroup
 //                      barrier per count and one per ordinary chunk.
@@ -323,7 +326,7 @@ struct PbOut {
 
 // What pb_singles_kernel hands to the chunk kernel: ONE contiguous record per frame (1536 B) with everything the search
 // needs, so that the receiving wavefront starts after a single wide load instead of the chain frame number -> source
-// index -> permutation -> y (round 3; the record replaces the separate 1096-byte PbPrep table of rounds 2-3):
+// index -> permutation -> y (round 4; the record replaces the separate 1096-byte per-frame table of rounds 2-3):
 //   words [0, 128)     w[128]     |y'|                                       } the head of PbWaveLds (behind its four pad
 //   words [128, 256)   P[64]      rows of P'                                 } words): the chunk kernel copies these 360 words
 //   words [256, 258)   0          the "row" an unused position of a key reads } into LDS as they are
@@ -1796,7 +1799,7 @@ static_assert(offsetof(PbWaveLds<kPbWaveCap>, cdfH) == kPbRecPrefix * 4 && offse
 //  phases do vanish from the stamps -- but the launch got SLOWER: 359 -> 423 us at 2.5 dB, 5.03 -> 5.07 ms at 1.0 dB.  A frame
 //  bound early to a wavefront that is busy with a long search starts late, and the launch is its tail: 3.4 frames per
 //  resident wavefront at 2.5 dB; the other wavefronts of the SIMD had been hiding those round trips anyway.)
-// (12.1 KiB of LDS per frame: 13 workgroups per CU; three wavefronts per SIMD asked of the register allocator)
+// (10 080 B of LDS per frame: 16 workgroups per CU; four wavefronts per SIMD asked of the register allocator: 128 VGPRs)
 template <int CAP, bool PROF, int ROT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb_wave_kernel(PbParams P,
                                                      const double *__restrict__ cdf_half, int *__restrict__ ctl,

@@ -17,7 +17,7 @@ struct StreamWs {
     int *d_pb_ctl = nullptr;          // PB-OSD: list lengths and tickets (kPbCtlInts ints, zeroed per call)
     int *d_pb_list = nullptr;         // PB-OSD: [2][kPbSub * pb_sub_cap] frames handed on: list A (chunk kernel), B (list replay)
     void *d_pb_carry = nullptr;       // PB-OSD: [kPbHeavyCap] records of the long searches handed to the workgroup kernel ("list C")
-    void *d_pb_prep = nullptr;        // PB-OSD: [pb_cap] per-frame probabilities / CDF table of the frames handed on (1 KiB each)
+    void *d_pb_prep = nullptr;        // PB-OSD: [pb_cap] records of the frames the singles kernel hands on (1536 B each: |y'|, P', CDF table, permutation, scalars)
     int64_t pb_cap = 0, pb_sub_cap = 0;
     void *d_pb_spill = nullptr;       // PB-OSD sequential kernel: frontier overflow [waves][stride]
     int64_t pb_spill_stride = 0;
