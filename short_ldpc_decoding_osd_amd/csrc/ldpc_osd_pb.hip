@@ -812,7 +812,14 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int
     int head = 0;
     while (head < tail && cnt <= KCAP) {
         if constexpr (PROF) pt[kPwTrips] += 1;
-        const int e = head + lane;
+        // A trip serves up to 64 entries, two members each.  When fewer than 33 entries wait -- the tail of a walk: a few long
+        // items -- every entry gets 2, 4 or 8 lanes, lane u of its group taking the members 2u and 2u + 1 below the cursor:
+        // inside an item the sums rise as the position falls, so the members <= T are a PREFIX and every lane judges its two
+        // by itself; the group's leader steps the cursor by what the group emitted.  (Two members per entry and trip whatever
+        // the list's length: 9.3 trips per chunk at 1.0 dB, half of them at a tenth of the lanes.)
+        const int nent = tail - head;
+        const int gs = (nent > 32 || cnt > KCAP - 128) ? 0 : (nent > 16 ? 1 : (nent > 8 ? 2 : 3));      // log2 of the lanes per entry
+        const int e = head + (lane >> gs), u = lane & ((1 << gs) - 1);
         const bool has = e < tail;
         const unsigned ent = has ? list[ring(e)] : 0u;
         const int q = (int)(ent & 31u), l = (int)((ent >> 5) & 63u);
@@ -830,21 +837,27 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int
         unsigned char *const cb = reinterpret_cast<unsigned char *>(&L.cur[q >> 2][l]) + (q & 3);
         const int a = has ? (int)*cb : 1;
         const float sbv = q < 31 ? w[i] + w[j] : (l <= 62 ? w[l] : 0.0f);
-        // up to TWO members of the item per trip (the tail of a walk is a few long items: half the trips); the order of the
-        // keys inside a chunk is irrelevant, so the second members simply follow the first ones
-        const int m = a - 1;
-        const float s = sbv + w[m], s2 = sbv + w[m > 0 ? m - 1 : 0], s3 = sbv + w[m > 1 ? m - 2 : 0];
-        const bool two = has && m > base + 1 && s2 <= T && cnt <= KCAP - 64;      // (no second members in a trip that may end beyond KCAP + 63)
-        const int mlast = two ? m - 1 : m;
-        const bool left = mlast > base + 1;                 // the item has members beyond this trip's
-        const bool again = has && left && (two ? s3 : s2) <= T;
-        const u64 act = __ballot(has), act2 = __ballot(two);
+        // this lane's two members (the order of the keys inside a chunk is irrelevant: second members follow the first ones)
+        const int m = a - 1 - 2 * u;
+        const float s = sbv + w[m & 63], s2 = sbv + w[(m - 1) & 63];
+        const bool one = has && m > base && (u == 0 || s <= T);                   // (the group's first member is <= T: that is why the item is listed)
+        const bool two = one && m - 1 > base && s2 <= T && cnt <= KCAP - 64;       // (no second members in a trip that may end beyond KCAP + 63)
+        const u64 act = __ballot(one), act2 = __ballot(two);
+        // what the entry's group emitted (a prefix of the item's members below the cursor), its new cursor, and whether the
+        // member behind it is <= T too (then the entry is listed again)
+        const int gsh = (lane >> gs) << gs;
+        const u64 gm = gs == 0 ? 1ull : ((1ull << (1 << gs)) - 1ull);
+        const int k = __popcll((act >> gsh) & gm) + __popcll((act2 >> gsh) & gm);
+        const int mlast = a - k;                                                  // the lowest position emitted
+        const bool left = mlast > base + 1;                                       // the item has members beyond this trip's
+        const bool lead = has && u == 0;
+        const bool again = lead && left && sbv + w[(mlast - 1) & 63] <= T;
         const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, (unsigned)cnt));
         const int pos2 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act2, (unsigned)(cnt + __popcll(act))));
         const u64 more = __ballot(again);
         const int nt = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(more >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)more, 0u));
         wave_fence();                    // (every lane has read its entry: the slots may be written now)
-        if (has) {
+        if (one) {
             const unsigned tmpl = code;       // (the field of the LAST position is zero in it; unused fields hold 64)
             // frontier growth of the pop (pb_delta): the extended child exists below position 63 and below the order, the
             // adjacent child if the last position can move down by one; + 1, in bits 26-27
@@ -858,11 +871,16 @@ __device__ __forceinline__ int pbw_walk(PbWaveLds<CAP> &L, float T, int cnt, int
                 L.keys[pos] = ((u64)__float_as_uint(s) << 32) | (tmpl | g1 | ((unsigned)m << sh));
                 if (two) L.keys[pos2] = ((u64)__float_as_uint(s2) << 32) | (tmpl | g2 | ((unsigned)(m - 1) << sh));
             }
+        }
+        if (lead) {
             *cb = (unsigned char)(left ? mlast : 0);        // (0: exhausted -- the list pass then reads the NaN)
             if (again) list[ring(nt)] = ent;
         }
         cnt += __popcll(act) + __popcll(act2);
-        head = head + 64 < tail ? head + 64 : tail;
+        {
+            const int served = 64 >> gs;
+            head = head + served < tail ? head + served : tail;
+        }
         tail += __popcll(more);
         wave_fence();
         // (the next trip appends at tail .. tail + 63 while the entries head + 64 .. tail - 1 are still unread)
