@@ -313,13 +313,6 @@ __device__ bool pb_visit_less(const float *w, PbTep t, PbTep u)
         if (pb_same(t, u)) return kt < ku;
     }
 }
-__device__ __forceinline__ void pb_apply(const SearchLds &L, const PbTep &t, u64 d0, u64 &D, u64 &E)
-{
-    D = d0 ^ L.P[t.p0]; E = 1ull << t.p0;
-    if (t.wt > 1) { D ^= L.P[t.p1]; E |= 1ull << t.p1; }
-    if (t.wt > 2) { D ^= L.P[t.p2]; E |= 1ull << t.p2; }
-}
-
 struct PbOut {
     u64 *cw; float *metric; int *best, *ntep, *aux;
 };
@@ -360,7 +353,6 @@ __device__ __forceinline__ void pb_write(LDS &L, const SearchFrame &S, const PbO
 
 // inclusive wave scans (lane order)
 __device__ __forceinline__ float wave_incl_min(float v, int) { return wave_incl_min_dpp(v); }
-__device__ __forceinline__ int wave_incl_add(int v, int) { return wave_incl_add_dpp(v); }
 
 // ---------------------------------------------------------------------------------------
 // stage 1: the weight-1 head of the pop sequence, one frame per wavefront, one TEP per lane
