@@ -108,6 +108,16 @@ def test_generic_kernel_other_codes(name, alist):
     _check_against_oracle(d, y, 8, 0.75)
     with pytest.raises(_lib.LdpcError):
         d.nms(to_dev(y, d), 8, 0.75, kernel=_lib.NMS_QC16)
+    # the failed-frame rows (ldpc_nms_traj_rows) on this code's shape: rows of the listed frames = rows of the full trajectory
+    yd = to_dev(y, d)
+    res = d.nms(yd, 8, 0.75, want_traj=True)
+    index, count = d.compact(res["fail"])
+    nf = int(count.cpu()[0])
+    if nf:
+        rows = d.nms_traj_rows(yd, index, count, nf, 8, 0.75)
+        torch.cuda.synchronize()
+        idx = index[:nf].long()
+        assert torch.equal(rows, torch.cat([yd[idx].unsqueeze(1), res["traj"][:, idx, :].permute(1, 0, 2)], dim=1))
 
 
 def test_eval_counts_and_compaction(dec):
