@@ -201,6 +201,26 @@ __device__ __forceinline__ int ge_sign_mask(u64 c, int nshift)
     return m;
 }
 
+// m1 / m2 = -1 in the lanes whose column (C1 / C2, as two 32-bit halves) has a 1 in row pr -- wave-uniform, 0..63.  The half that
+// holds the row is picked by ONE scalar branch, then a signed one-bit field extract per column (v_bfe_i32 uses the low five bits
+// of its offset, so pr serves for either half): 2 vector + 3 scalar instructions per step, where the shift form (ge_sign_mask:
+// a 64-bit shift and an arithmetic shift per column) took 4 vector instructions.  Round 4: the front end's elimination loop
+// 12 -> 10 vector instructions per step.  (Written as one asm block: left to the compiler the two-sided branch cost nine
+// scalar instructions.)
+__device__ __forceinline__ void ge_row_masks(unsigned c1l, unsigned c1h, unsigned c2l, unsigned c2h, int pr, int &m1, int &m2)
+{
+    asm("s_cmp_lt_u32 %6, 32\n\t"
+        "s_cbranch_scc0 1f\n\t"
+        "v_bfe_i32 %0, %2, %6, 1\n\t"
+        "v_bfe_i32 %1, %4, %6, 1\n\t"
+        "s_branch 2f\n"
+        "1:\n\t"
+        "v_bfe_i32 %0, %3, %6, 1\n\t"
+        "v_bfe_i32 %1, %5, %6, 1\n"
+        "2:"
+        : "=&v"(m1), "=&v"(m2) : "v"(c1l), "v"(c1h), "v"(c2l), "v"(c2h), "s"(pr) : "scc");
+}
+
 __device__ __forceinline__ unsigned ge_xor_masked(unsigned c, int m, unsigned e)
 {
     asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x78" : "+v"(c) : "v"(m), "s"(e));   // c ^ (m & e)
@@ -261,7 +281,8 @@ __device__ __forceinline__ int ge_columns(u64 &C1, u64 &C2, int &rho, int &idx1,
         if (e != 0) {   // nothing to clear when the pivot column is already a unit vector (common: G = [P | I])
             const unsigned el = (unsigned)e, eh = (unsigned)(e >> 32);
             unsigned c1l = (unsigned)C1, c1h = (unsigned)(C1 >> 32), c2l = (unsigned)C2, c2h = (unsigned)(C2 >> 32);
-            const int m1 = ge_sign_mask(C1, npr), m2 = ge_sign_mask(C2, npr);
+            int m1, m2;      // -1 in the lanes whose column has a 1 in the pivot row
+            ge_row_masks(c1l, c1h, c2l, c2h, pr, m1, m2);
             c1l = ge_xor_masked(c1l, m1, el); c1h = ge_xor_masked(c1h, m1, eh);
             c2l = ge_xor_masked(c2l, m2, el); c2h = ge_xor_masked(c2h, m2, eh);
             C1 = ((u64)c1h << 32) | c1l;
