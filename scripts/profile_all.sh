@@ -26,6 +26,7 @@ want() { [ $# -eq 0 ] && return 0; local n=$1; shift; for w in "$@"; do [ "$w" =
 SEL="$@"
 sel() { if [ -z "$SEL" ]; then return 0; fi; for w in $SEL; do [ "$w" = "$1" ] && return 0; done; return 1; }
 sel nms10_osd2 && run nms10_osd2 131072
+sel nms10_osd2_fused && run nms10_osd2_fused 131072 --osd-route decode
 sel nms10 && run nms10 65536 --workload nms10
 sel nms10_osd0 && run nms10_osd0 65536 --workload nms10_osd0
 sel nms10_fs2 && run nms10_fs2 131072 --workload nms10_fs2
