@@ -90,7 +90,7 @@ struct PbParams {
     int t3, budget;              // chunk target of the workgroup kernel; TEPs after which a frame may be handed to it
     int budget_s, budget_m;      // ... when its sub-list is short (< 128 frames) / of medium length (< 448)
     int budget_l, budget_xl;     // ... long (1400 .. 3000) / very long
-    int late_min, late_maxlen, late_pct, late_div;   // frames of list A beyond late_pct % of a sub-list (if the list holds more than late_min frames) leave after budget / late_div
+    int late_min, late_maxlen, late_pct, late_div;   // once late_pct % of a sub-list's frames have STARTED (lists of more than late_min frames in all, sub-lists shorter than late_maxlen) a search leaves after budget / late_div
     int handoff_maxlen;          // ... if its sub-list of list A holds fewer frames than this (many searches: throughput counts, none leaves)
     float c4;
     long long cmin_off;          // offset of the spilled chunk minima inside a wave's global area
@@ -1839,8 +1839,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
             if (lane < 4) L.pre[lane] = pbw_nan();
             have_cdfh = true;
         }
-        // (a frame that starts late -- its workgroup waited for a slot -- would end the launch if it ran long here: it leaves sooner)
-        const int budget = (len * kPbSub > P.late_min && len < P.late_maxlen && k * 100 >= len * P.late_pct) ? budget0 / P.late_div : budget0;
+        // The launch's TAIL: once the dispatcher has no frame left to hand out, every search that goes on here keeps its CU
+        // from idling only by itself -- the launch then lasts as long as the longest of them (measured with the frames sorted by
+        // search length, which no product path can do: 260 -> 204 us at 2.5 dB, 3.62 -> 3.18 ms at 1.0 dB).  So the frames count
+        // themselves in as they start, and a search that finds (after a chunk) that its whole sub-list has started -- the
+        // sub-lists advance side by side: workgroup b serves entry b / 16 of sub-list b mod 16 -- leaves for the workgroup
+        // kernel after budget / late_div TEPs instead of budget.  WHERE a search is handed on depends on timing then; what it
+        // returns does not (tests/test_gpu_osd_pb.py runs the kernels under several schedules).
+        int *const finished = &ctl[kPbCtlStartA + kPbCtlLine * sub];
+        const bool tail_rule = len * kPbSub > P.late_min && len < P.late_maxlen;
+        const int tail_budget = budget0 / P.late_div;
+        const long long tail_slots = 4096ll * P.late_pct;       // (256 CUs x 16 wavefronts of this kernel, in per cent)
         const long long f = listA[sub * sub_cap + k];
         // ---- per-frame set-up: ONE wide load of the record pb_singles_kernel wrote (|y'|, P', the CDF table, the permutation: 356
         // words, copied into LDS as they are), the frame's scalars by scalar loads; derived here: the cost-bound table, the
@@ -1907,6 +1916,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
         while (state == 0 && done < nall) {
             float T;
             int nwalks = 0;
+            // (the tail rule's counter, asked for here and looked at after the chunk: the round trip hides behind the walk)
+            int nstarted = 0;
+            if (tail_rule && !asked) nstarted = __hip_atomic_load(finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // a chunk of 4-byte keys (up to 2 CAP + 64 of them); W.ecur keeps the cursors it started from until it is judged
             const int n = pbw_next_chunk<CAP, PROF, ROT, true, false>(L, W, P.order, lo, done, nall, firstc ? P.t1 : P.t2, lane, T, tprev, nprev, nwalks, pt);
             firstc = false;
@@ -1926,6 +1938,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
             pbw_cursors_load<CAP>(L, W.ecur, lane);          // commit (L.cur: the cursors behind the chunk, whoever walked it)
             lo = T;
             done += n;
+            const int budget = (tail_rule && (long long)(len - nstarted) * kPbSub * 100 <= tail_slots) ? tail_budget : budget0;
             if (state == 0 && done >= budget && !asked && done < nall && len < P.handoff_maxlen) {
                 // a long search: the workgroup kernel takes it over if it still has room (at most kPbHeavyCap frames a call)
                 asked = true;
@@ -1970,6 +1983,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
             PBW_STAMP(kPwStore);
             if constexpr (PROF) pt[kPwFrames] += 1;
         }
+        if (lane == 0) atomicAdd(finished, 1);
         wave_fence();
     }
     if constexpr (PROF) { if (lane0 == 0 && pt[kPwFrames]) for (int k = 0; k < kPwSlots; ++k) atomicAdd(&prof_out[k], pt[k]); }
@@ -2855,7 +2869,7 @@ ldpc_pb_tuning pb_default_tuning()
     ldpc_pb_tuning t;
     t.budget = 4096; t.budget_s = t.budget / 8; t.budget_m = t.budget / 4; t.budget_l = 2 * t.budget; t.budget_xl = 6 * t.budget;
     t.t1 = 320; t.t2 = 600; t.t3 = 3072;        // (t2 measured at 1.0 / 2.5 dB: 512: 4.16 / 0.548 ms, 600: 4.08 / 0.532, 676: 4.11 / 0.554, 760: 4.37 / 0.561)
-    t.late_min = 4608; t.late_maxlen = 4400; t.late_pct = 1000; t.late_div = 4;
+    t.late_min = 4608; t.late_maxlen = 1 << 30; t.late_pct = 40; t.late_div = 8;
     t.handoff_maxlen = 1 << 30;
     return t;
 }

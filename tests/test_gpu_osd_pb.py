@@ -146,15 +146,17 @@ def test_pb_tuning_is_validated(dec):
     assert dec.pb_tuning()["t2"] == 256
     dec.set_pb_tuning()
     assert dec.pb_tuning() == before == dict(budget=4096, budget_s=512, budget_m=1024, budget_l=8192, budget_xl=24576, t1=320, t2=600,
-                                             t3=3072, late_min=4608, late_maxlen=4400, late_pct=1000, late_div=4, handoff_maxlen=1 << 30)
+                                             t3=3072, late_min=0, late_maxlen=1 << 30, late_pct=100, late_div=4, handoff_maxlen=1 << 30)
 
 
 @pytest.mark.parametrize("tuning", [dict(t1=32, t2=32), dict(t1=832, t2=832), dict(t1=64, t2=800, budget_s=100000, budget_m=100000, budget=100000),
-                                    dict(t1=500, t2=97, budget_s=300, budget_m=300, budget=300, t3=256)])
+                                    dict(t1=500, t2=97, budget_s=300, budget_m=300, budget=300, t3=256),
+                                    dict(late_pct=0, late_div=64), dict(late_pct=50, late_div=8, t2=200), dict(late_div=1)])
 def test_pb_results_do_not_depend_on_the_tuning(dec, tuning):
     """Chunk targets at both ends of their range (tiny chunks; chunks that overflow the 832-key buffer and the work-list ring and
     are retried; a chunk extended in place), with and without hand-over to the workgroup kernel: counts, stops, winners and
-    metrics stay exact (the bounds of a chunk are free parameters of the method)."""
+    metrics stay exact (the bounds of a chunk are free parameters of the method).  The last three: the tail rule of the chunk
+    kernel (searches leave sooner once their sub-list has started) from the first frame on / from half way / off."""
     prev = dec.set_pb_tuning(**tuning)
     try:
         y, cw = _failures(dec, 1.5, 900, seed=21)
