@@ -1795,6 +1795,7 @@ struct PbCarry {
     long long f;
     float tprev, nprev;      // the last chunk's lower bound and the TEPs before it (the growth exponent for the next bound)
 };
+constexpr int kPbFarProbe = 8;
 constexpr int kPbRecPrefix = 496, kPbRecCur = 496, kPbRecScalars = 1008, kPbRecWords = 1040;
 constexpr int kPbRecPerm = 330;       // (the permutation bytes inside the prefix: PbWaveLds::perm)
 static_assert(kPbRecScalars * 4 % 8 == 0 && kPbRecScalars * 4 + sizeof(PbCarry) <= kPbRecWords * 4, "record layout");
@@ -1940,12 +1941,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
             done += n;
             const int budget = (tail_rule && (long long)(len - nstarted) * kPbSub * 100 <= tail_slots) ? tail_budget : budget0;
             if (state == 0 && done >= budget && !asked && done < nall && len < P.handoff_maxlen) {
-                // a long search: the workgroup kernel takes it over if it still has room (at most kPbHeavyCap frames a call)
+                // a long search: the workgroup kernel takes it over if it still has room (at most kPbCoopHalf frames per half of list C and call)
                 asked = true;
+                // The workgroup kernel's launch is as long as its last frame: it serves first the searches that will run far.
+                // Rule 1 (acquire_prob_promising) against the best so far, at 64 sums between here and the largest sum: a
+                // search whose rule cannot fire in the first kPbFarProbe of them goes into the first half of list C (an
+                // improvement of the best only shortens a search: the long ones are all there).  Per search call, all in one
+                // half / threshold 6 / 8 / 12 (means over four batches x 12 launches: single launches scatter by +-15 %, where a
+                // search is handed on depends on timing): 2.5 dB 0.479 / 0.469 / 0.475 / 0.468 ms, 2.0 dB 0.988 / 0.963 / 0.955 / 0.970,
+                // 1.0 dB 3.80 / 3.76 / 3.75 / 3.75.
+                int far;
+                {
+                    const float rp = lo + (smax - lo) * ((float)(lane + 1) * (1.0f / 64.0f));
+                    float w1;
+                    const float bs = pb_promising_bs(rp, S.best, Fr, P.c4, L.cdfA, L.cdfH, w1);
+                    const u64 fires = __ballot((double)bs < Fr.p_t_pro);
+                    far = (fires ? __builtin_ctzll(fires) : 64) >= kPbFarProbe;
+                }
                 int slot = 0;
-                if (lane == 0) slot = atomicAdd(&ctl[kPbCtlLenC], 1);
+                if (lane == 0) slot = atomicAdd(&ctl[far ? kPbCtlLenC : kPbCtlLenC2], 1);
                 slot = __builtin_amdgcn_readfirstlane(slot);
-                if (slot < kPbHeavyCap) {
+                if (slot < kPbCoopHalf) {
+                    if (!far) slot += kPbCoopHalf;
                     unsigned *const crec = carry + (long long)slot * kPbRecWords;
                     const unsigned *const Lw = reinterpret_cast<const unsigned *>(&L);
                     for (int k = lane; k < kPbRecPrefix; k += 64) crec[k] = Lw[k];
@@ -2545,8 +2562,10 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
     constexpr int NI = 32 / NW;
     static_assert(64 * NW >= 64 + kPbRecPrefix, "wavefronts 1.. copy a record's tables in one go");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lenc = ctl[kPbCtlLenC];
-    const int nlist = lenc < kPbCoopFrames ? lenc : kPbCoopFrames;
+    // list C: ticket t < nfar -> record t (the searches expected to run far), the others -> record kPbCoopHalf + (t - nfar)
+    const int lenc = ctl[kPbCtlLenC], lenc2 = ctl[kPbCtlLenC2];
+    const int nfar = lenc < kPbCoopHalf ? lenc : kPbCoopHalf;
+    const int nlist = nfar + (lenc2 < kPbCoopHalf ? lenc2 : kPbCoopHalf);
     if ((int)blockIdx.x >= nlist) return;      // (more workgroups than frames -- or nothing handed on at all: leave before any set-up)
     const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);
     if (wave == 0) {
@@ -2561,7 +2580,7 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
         if (tk >= nlist) break;
         int next_tk = 0;      // (drawn now, parked in LDS at the frame's end: the wavefront does not wait for the atomic here)
         if (tid == 0) { next_tk = atomicAdd(&ctl[kPbCtlTicketC], 1); L.ncand[0] = 0; L.ncand[1] = 0; }
-        const unsigned *rec = carry + (long long)tk * kPbRecWords;
+        const unsigned *rec = carry + (long long)(tk < nfar ? tk : kPbCoopHalf + (tk - nfar)) * kPbRecWords;
         // the frame's tables: one load per thread (wavefront 0 may still be writing the previous frame's codeword out)
         if (tid >= 64 && tid < 64 + kPbRecPrefix) reinterpret_cast<unsigned *>(&L.one)[tid - 64] = rec[tid - 64];
         const PbCarry &c = *reinterpret_cast<const PbCarry *>(rec + kPbRecScalars);
@@ -2605,6 +2624,11 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
             state = coop_scan_chunk<NW, PROF>(L, R, P, Fr, d0, n, kbase, kcount, cmn, cmx, lane, wave, S, stop, ntep, Q);
             PBC_STAMP(kPcScan);
             if (state < 0) {
+                // (One wavefront redoing ~2700 keys alone takes 35-135 us where the whole launch takes ~150, in-kernel stamps of
+                //  round 4.  Measured and dropped: walking the same sums again with a third of the target, all wavefronts
+                //  together, until <= 768 keys are left for wavefront 0 -- the failing chunk is walked ~8 times on the way down,
+                //  the solo stamp falls from 630 k to 180 k cycles per launch and the launch gets LONGER: 0.479 -> 0.500 ms per
+                //  search call at 2.5 dB, no change at 2.0 / 1.0 dB.)
                 PBC_COUNT(kPcSolos, 1); PBC_COUNT(kPcSoloKeys, n);
                 // wavefront 0 redoes the chunk alone from the cursors the chunk started with
 #pragma unroll
@@ -2632,7 +2656,7 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
                     for (int j = 0; j < NI; ++j) I.a[j] = L.sv[j][lane];
                     Fr = L.su.fr; d0 = L.su.d0; lo = L.su.lo; T = L.su.T; tprev = L.su.tprev; nprev = L.su.nprev; smax = L.su.smax;
                     done = L.su.done; n = L.su.n; R.seq = L.su.seq; R.par = L.su.par; it = L.su.it; tk = L.su.tk;
-                    rec = carry + (long long)tk * kPbRecWords;
+                    rec = carry + (long long)(tk < nfar ? tk : kPbCoopHalf + (tk - nfar)) * kPbRecWords;
                     po = rec[kPbRecPerm + (lane >> 2)]; po2 = rec[kPbRecPerm + 16 + (lane >> 2)];
                     next_tk = L.su.next_tk;
                 }
@@ -2869,7 +2893,9 @@ ldpc_pb_tuning pb_default_tuning()
     ldpc_pb_tuning t;
     t.budget = 4096; t.budget_s = t.budget / 8; t.budget_m = t.budget / 4; t.budget_l = 2 * t.budget; t.budget_xl = 6 * t.budget;
     t.t1 = 320; t.t2 = 600; t.t3 = 3072;        // (t2 measured at 1.0 / 2.5 dB: 512: 4.16 / 0.548 ms, 600: 4.08 / 0.532, 676: 4.11 / 0.554, 760: 4.37 / 0.561)
-    t.late_min = 4608; t.late_maxlen = 1 << 30; t.late_pct = 40; t.late_div = 8;
+    // (the tail rule, means over four batches x 12 launches per search call at 2.5 / 2.0 / 1.0 dB: off 0.504 / 1.057 / 4.153 ms, 40 % and
+    //  budget / 8: 0.476 / 0.964 / 3.779, / 16: 0.473 / 0.960 / 3.765, / 4: 0.480 / 0.967 / 3.824, 25 %: 0.462 / 0.966 / 3.788, 60 %: 0.473 / 0.982 / 3.824)
+    t.late_min = 4608; t.late_maxlen = 1 << 30; t.late_pct = 40; t.late_div = 16;
     t.handoff_maxlen = 1 << 30;
     return t;
 }
@@ -2958,7 +2984,7 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     pp.order = p->order; pp.nmax = (int)nmax; pp.cmin_off = spill_slots;
     // When a search leaves the chunk kernel for the workgroup kernel: after `budget` TEPs, the budget chosen ON THE DEVICE from the
     // length of the frame's sub-list of list A (a sixteenth of the frames that search beyond the weight-1 head), so that the
-    // workgroup kernel gets the tails, 1000-3500 frames a call, and never the bulk (its list holds kPbHeavyCap frames).
+    // workgroup kernel gets the tails, 1000-3500 frames a call, and never the bulk (its list holds 2 x kPbCoopHalf frames).
     // Measured per 131 072-frame step (round 3), PB kernels with the budget of the schedule / the neighbouring ones / no hand-over:
     //   3.5 dB (length 42)    512: 0.20 ms              2.0 dB  (1750)   8192: 1.50 | 4096: 1.52 | 16384: 1.61 | none 1.80
     //   3.0 dB (177)         1024: 0.34                 1.75 dB (2560)   8192: 2.20 | 16384: 2.26 | 4096: 2.91 | none 2.50
@@ -3039,7 +3065,7 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
         fprintf(stderr, "\n");
     }
 #undef PB_WAVE_LAUNCH
-    // the long searches the chunk kernel handed on (at most kPbHeavyCap; the workgroups find an empty list otherwise)
+    // the long searches the chunk kernel handed on (at most kPbHeavyCap, in two halves; the workgroups find an empty list otherwise)
     const unsigned g4 = (unsigned)(F < kPbCoopGrid ? F : kPbCoopGrid);
     if (!profile_s) {
         hipLaunchKernelGGL((pb_coop_kernel<kPbCoopW, false>), dim3(g4), dim3(64 * kPbCoopW), sizeof(PbCoopLds<kPbCoopW>), s,

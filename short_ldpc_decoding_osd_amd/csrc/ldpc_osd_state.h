@@ -32,9 +32,10 @@ constexpr int kPbSub = 16, kPbCtlLine = 32;
 constexpr int kPbCtlLenA = 0, kPbCtlLenB = kPbSub * kPbCtlLine, kPbCtlTicketB = kPbCtlLenB + kPbCtlLine;
 constexpr int kPbCtlLenC = kPbCtlTicketB + kPbCtlLine, kPbCtlTicketC = kPbCtlLenC + kPbCtlLine;
 constexpr int kPbCtlStartA = kPbCtlTicketC + kPbCtlLine;      // [kPbSub] lines: frames of a sub-list the chunk kernel has STARTED (its tail rule)
-constexpr int kPbCtlInts = kPbCtlStartA + kPbSub * kPbCtlLine;
-constexpr int kPbHeavyCap = 4096;     // long searches a call may hand to the workgroup-per-frame kernel
-constexpr int kPbCoopFrames = kPbHeavyCap;
+constexpr int kPbCtlLenC2 = kPbCtlStartA + kPbSub * kPbCtlLine;   // list C's second half: the searches expected to be short
+constexpr int kPbCtlInts = kPbCtlLenC2 + kPbCtlLine;
+constexpr int kPbCoopHalf = 4096;     // long searches a call may hand to the workgroup-per-frame kernel: this many expected to run
+constexpr int kPbHeavyCap = 2 * kPbCoopHalf;      // to the end of the table (served first) + this many others
 constexpr int kPbSeqBlocks = 64;      // grid of the sequential PB kernel (each of its 4 x 64 waves owns a spill area)
 
 struct OsdState {

@@ -116,17 +116,18 @@ def test_pb_other_input_scalings(dec, scale):
 
 
 def test_pb_workgroup_kernel_overflowing_hand_over(dec):
-    """The workgroup kernel takes at most 4096 searches a call: with the hand-over budget forced to 64 TEPs (the context's
-    tuning, ldpc_ctx_set_pb_tuning) more than that ask to leave the chunk kernel -- the first 4096 are finished by the workgroup
-    kernel from their first chunks on, the others stay where they are.  Same counts, stops, winners and metrics."""
+    """The workgroup kernel takes at most 2 x 4096 searches a call (its list has two halves: searches expected to run far, served
+    first, and the others): with the hand-over budget forced to 64 TEPs (the context's tuning, ldpc_ctx_set_pb_tuning) more than
+    that ask to leave the chunk kernel, so at least one half overflows -- the searches that find room are finished by the
+    workgroup kernel from their first chunks on, the others stay where they are.  Same counts, stops, winners and metrics."""
     prev = dec.set_pb_tuning(budget_s=64, budget_m=64, budget=64, budget_l=64, budget_xl=64)
     try:
         assert dec.pb_tuning()["budget_xl"] == 64
-        y, cw = _failures(dec, 1.5, 14000, seed=5)
-        y, cw = y[:8000], cw[:8000]
-        assert y.shape[0] == 8000
+        y, cw = _failures(dec, 1.5, 30000, seed=5)
+        y, cw = y[:18000], cw[:18000]
+        assert y.shape[0] == 18000
         ref = _check(dec, y, cw, 3, 1.5, None)
-        assert (ref["num_teps"] > 64).sum() > 4096 + 200
+        assert (ref["num_teps"] > 64).sum() > 2 * 4096 + 200
     finally:
         dec.set_pb_tuning(**prev)
     assert dec.pb_tuning() == prev
@@ -146,7 +147,7 @@ def test_pb_tuning_is_validated(dec):
     assert dec.pb_tuning()["t2"] == 256
     dec.set_pb_tuning()
     assert dec.pb_tuning() == before == dict(budget=4096, budget_s=512, budget_m=1024, budget_l=8192, budget_xl=24576, t1=320, t2=600,
-                                             t3=3072, late_min=0, late_maxlen=1 << 30, late_pct=100, late_div=4, handoff_maxlen=1 << 30)
+                                             t3=3072, late_min=4608, late_maxlen=1 << 30, late_pct=40, late_div=16, handoff_maxlen=1 << 30)
 
 
 @pytest.mark.parametrize("tuning", [dict(t1=32, t2=32), dict(t1=832, t2=832), dict(t1=64, t2=800, budget_s=100000, budget_m=100000, budget=100000),
