@@ -2312,6 +2312,13 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
         return D;
     };
     const auto sumbits = [](u64 key) { return (unsigned)(key >> 32); };
+    // a is visited before b (a != b): by sum, equal sums by the list-slot order (pb_visit_less: through the parents).  Round 4: a tie
+    // against a reference key used to send the whole chunk, ~2700 keys, to wavefront 0 alone -- 1-4 times per launch at 2.5 dB,
+    // 35-135 us each where the launch takes ~150.
+    const auto visited_before = [&](u64 a, u64 b) {
+        if (sumbits(a) != sumbits(b)) return sumbits(a) < sumbits(b);
+        return pb_visit_less(T0.w, pbw_tep((unsigned)a), pbw_tep((unsigned)b));
+    };
     const auto key_at = [&](int k) { const int i = k * 64 + lane; return i < kcount ? L.keys[kbase + i] : ~0ull; };   // (an empty slot: all ones, sum NaN)
     int sumdel = 0, neg = 0, nsurv = 0;
     unsigned fs = 0x7FFFFFFFu;     // the smallest sum on which rule 1 fires (against the chunk-start best)
@@ -2419,7 +2426,7 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
         const float myc = lane < ncand ? L.cc[lane] : 0.0f;
         int rk0 = 0;
         bool t0 = false;
-        for (int d = 0; d < ncand; ++d) { const u64 o = L.ck[d]; rk0 += sumbits(o) < sumbits(my); t0 |= lane < ncand && sumbits(o) == sumbits(my) && o != my; }
+        for (int d = 0; d < ncand; ++d) { const u64 o = L.ck[d]; rk0 += lane < ncand && o != my && visited_before(o, my); }
         wave_fence();
         if (lane < ncand) { L.ck[rk0] = my; L.cc[rk0] = myc; }
         wave_fence();
@@ -2466,7 +2473,7 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
                 const bool behind = key != ~0ull && sumbits(key) >= s0;
                 int t = 0;
                 if (behind)
-                    for (int u = 0; u < nrec; ++u) { const u64 r = L.rk[u]; t += sumbits(r) < sumbits(key); tie |= sumbits(r) == sumbits(key) && r != key; }
+                    for (int u = 0; u < nrec; ++u) { const u64 r = L.rk[u]; t += r != key && visited_before(r, key); }
                 const bool need = behind && __uint_as_float(sumbits(key)) > r_safe2;
                 if (__ballot(need)) {
                     float w1;      // (the first record itself is judged with the chunk-start best: t = 0)
@@ -2480,10 +2487,14 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
     PBC_STAMP(kPcSMin);
     int reason = 0;
     unsigned sstop = 0;
-    if (sF != 0x7FFFFFFFu) { reason = 1; sstop = sF; }
+    if (sF != 0x7FFFFFFFu) {
+        reason = 1; sstop = sF;
+        // ("the first key of the smallest firing sum stops" holds when every key of that sum sees the same best: not with a
+        //  record among them)
+        for (int u = 0; u < nrec; ++u) tie |= sumbits(L.rk[u]) == sF;
+    }
     if (stop2) {
         const unsigned sR = sumbits(L.rk[nrec - 1]);
-        if (reason == 1 && sR == sF) tie = true;
         if (reason == 0 || sR < sF) { reason = 2; sstop = sR; }
     }
     int nbefore = nrec;
@@ -2500,7 +2511,7 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
     for (int k = 0; k < PER; ++k) {
         if (k * 64 < kcount) {
             const u64 key = key_at(k);
-            if (nbefore > 0) { cb += sumbits(key) < sumbits(bk); tie |= sumbits(key) == sumbits(bk) && key != bk; }
+            if (nbefore > 0) cb += key != bk && visited_before(key, bk);
             if (reason == 1) cs += sumbits(key) < sstop;
         }
     }
