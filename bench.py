@@ -86,6 +86,9 @@ def parse_args(argv=None):
                     help="how the OSD stage of a step is issued: 'decode' = ldpc_osd_decode inside ldpc_pipeline_run (conventional order 2: "
                          "ONE fused front-end + scan kernel, nothing written to a workspace; other searches: front end into the "
                          "stream's workspace, then the search); 'front+search' = the two kernels through caller buffers, timed apart")
+    ap.add_argument("--pb-tuning", default="",
+                    help="PB-OSD tuning of the context, e.g. 'late_div=1,t2=512' (ldpc_ctx_set_pb_tuning; changes no result, "
+                         "only how searches are cut into chunks and handed on); recorded in the line's config")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams of the timed region; >1 keeps several batches in flight (batch i runs on stream i mod N)")
     return ap.parse_args(argv)
@@ -433,6 +436,8 @@ def run_rank(args):
     B = args.batch or default_batch
     nb = max(1, args.batches, args.streams)
     dec = Decoder(Code(), local_rank)
+    if args.pb_tuning:
+        dec.set_pb_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.pb_tuning.split(","))})
     algo = OSD_ALGO.get(args.workload, 0)
     pipes = []
     for i in range(nb):                                # distinct batches, each with its own buffers
@@ -592,7 +597,8 @@ def run_rank(args):
                    "rccl_ranks": dist.get_world_size() if dist is not None else 1,
                    "distinct_batches_per_gpu": nb, "distinct_frames": int(d[0]),
                    "bytes_in_plus_out_per_rotation": int(nb * B * (NMS_BYTES_PER_FRAME + 1)),
-                   "nms_kernel": {1: "generic", 2: "qc16"}[dec.nms_kernel], "streams": len(streams), "osd_route": args.osd_route},
+                   "nms_kernel": {1: "generic", 2: "qc16"}[dec.nms_kernel], "streams": len(streams), "osd_route": args.osd_route,
+                   **({"pb_tuning": dec.pb_tuning()} if algo == OSD_ALGO.get("nms10_pb3") else {})},
         "fer": {"frames": int(d[0]), "nms_frame_error_rate": d[1] / max(d[0], 1), "nms_syndrome_fail_rate": d[4] / max(d[0], 1),
                 "nms_undetected": int(d[3]), "nms_ber": d[2] / max(d[0] * dec.n, 1)},
     }

@@ -228,7 +228,7 @@ typedef struct ldpc_osd_params {
  *                  the launch's tail: once the frames of a sub-list that have not finished are fewer than late_pct % of
  *                  the chip's wavefront slots (a sixteenth of 4096), a search leaves after budget / late_div TEPs, for
  *                  lists of more than late_min frames and sub-lists shorter than late_maxlen; late_div = 1 switches
- *                  it off.  Defaults 4608, 2^30, 40, 16.  With it, WHERE a search is handed on depends on timing.
+ *                  it off.  Defaults 4608, 2^30, 20, 16.  With it, WHERE a search is handed on depends on timing.
  *   handoff_maxlen no search is handed on when the sub-list holds this many frames or more (default 2^30)
  * ldpc_ctx_set_pb_tuning validates (LDPC_E_ARG, nothing changed) and stores a copy; NULL restores the defaults.  It
  * applies to decode calls ISSUED afterwards (a captured graph keeps the values it was captured with); call it from

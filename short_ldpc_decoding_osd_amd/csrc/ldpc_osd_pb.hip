@@ -1843,10 +1843,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
         // The launch's TAIL: once the dispatcher has no frame left to hand out, every search that goes on here keeps its CU
         // from idling only by itself -- the launch then lasts as long as the longest of them (measured with the frames sorted by
         // search length, which no product path can do: 260 -> 204 us at 2.5 dB, 3.62 -> 3.18 ms at 1.0 dB).  So the frames count
-        // themselves in as they start, and a search that finds (after a chunk) that its whole sub-list has started -- the
-        // sub-lists advance side by side: workgroup b serves entry b / 16 of sub-list b mod 16 -- leaves for the workgroup
-        // kernel after budget / late_div TEPs instead of budget.  WHERE a search is handed on depends on timing then; what it
-        // returns does not (tests/test_gpu_osd_pb.py runs the kernels under several schedules).
+        // themselves out as they finish, and a search that finds (after a chunk) that fewer frames of its sub-list are unfinished
+        // than late_pct % of the chip's wavefront slots -- the sub-lists advance side by side: workgroup b serves entry b / 16 of
+        // sub-list b mod 16 -- leaves for the workgroup kernel after budget / late_div TEPs instead of budget.  WHERE a search is
+        // handed on depends on timing then; what it returns does not (tests/test_gpu_osd_pb.py runs the kernels under several
+        // schedules).
         int *const finished = &ctl[kPbCtlStartA + kPbCtlLine * sub];
         const bool tail_rule = len * kPbSub > P.late_min && len < P.late_maxlen;
         const int tail_budget = budget0 / P.late_div;
@@ -2904,9 +2905,12 @@ ldpc_pb_tuning pb_default_tuning()
     ldpc_pb_tuning t;
     t.budget = 4096; t.budget_s = t.budget / 8; t.budget_m = t.budget / 4; t.budget_l = 2 * t.budget; t.budget_xl = 6 * t.budget;
     t.t1 = 320; t.t2 = 600; t.t3 = 3072;        // (t2 measured at 1.0 / 2.5 dB: 512: 4.16 / 0.548 ms, 600: 4.08 / 0.532, 676: 4.11 / 0.554, 760: 4.37 / 0.561)
-    // (the tail rule, means over four batches x 12 launches per search call at 2.5 / 2.0 / 1.0 dB: off 0.504 / 1.057 / 4.153 ms, 40 % and
-    //  budget / 8: 0.476 / 0.964 / 3.779, / 16: 0.473 / 0.960 / 3.765, / 4: 0.480 / 0.967 / 3.824, 25 %: 0.462 / 0.966 / 3.788, 60 %: 0.473 / 0.982 / 3.824)
-    t.late_min = 4608; t.late_maxlen = 1 << 30; t.late_pct = 40; t.late_div = 16;
+    // The tail rule.  One search call at a time (means over four batches x 12 launches, ms at 2.5 / 2.0 / 1.0 dB): off 0.484 / 1.020 / 4.159,
+    // 10 %: 0.451 / 0.967 / 3.852, 20 %: 0.431 / 0.948 / 3.790, 30 %: 0.424 / 0.929 / 3.775, 40 %: 0.436 / 0.926 / 3.753 (budget / 16; / 8 and / 4
+    // within 1 %).  Four batches in flight (bench.py's graph, 10^8 frames/s at 2.5 / 2.0 dB, 10^7 at 1.0 dB), where the tails hide behind
+    // the other batches and the total work counts: off 2.715 / 1.335 / 3.30, 15 %: 2.708 / 1.324 / 3.357, 25 %: 2.670 / 1.311 / 3.343,
+    // 40 %: 2.626 / - / 3.31.  20 %: a tenth off a lone call, one per cent off the throughput at 2.5 dB, one per cent on it at 1.0 dB.
+    t.late_min = 4608; t.late_maxlen = 1 << 30; t.late_pct = 20; t.late_div = 16;
     t.handoff_maxlen = 1 << 30;
     return t;
 }

@@ -147,7 +147,7 @@ def test_pb_tuning_is_validated(dec):
     assert dec.pb_tuning()["t2"] == 256
     dec.set_pb_tuning()
     assert dec.pb_tuning() == before == dict(budget=4096, budget_s=512, budget_m=1024, budget_l=8192, budget_xl=24576, t1=320, t2=600,
-                                             t3=3072, late_min=4608, late_maxlen=1 << 30, late_pct=40, late_div=16, handoff_maxlen=1 << 30)
+                                             t3=3072, late_min=4608, late_maxlen=1 << 30, late_pct=20, late_div=16, handoff_maxlen=1 << 30)
 
 
 @pytest.mark.parametrize("tuning", [dict(t1=32, t2=32), dict(t1=832, t2=832), dict(t1=64, t2=800, budget_s=100000, budget_m=100000, budget=100000),
