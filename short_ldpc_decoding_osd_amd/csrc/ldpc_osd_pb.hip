@@ -131,17 +131,40 @@ struct PbFrame {
 
 // One wavefront: q[p] = sigmoid(c4 |y'_p|), the binomial CDF table of the mean LRB error probability and
 // the two thresholds.  w = |y'| (LDS) must be in place; q / cdfA are per-frame LDS arrays.
+// `pairs` (optional, [4][64] float2 of LDS): the four chains' (multiplier, addend) per step, written side by side here so that a
+// step of the chains is ONE instruction (see below); without it the operands are formed per step.
 __device__ __forceinline__ PbFrame pb_frame_setup(const float *w, float *q, double *cdfA, float c4, int order, int nmax, int lane,
-                                                  float best0 = __builtin_inff())
+                                                  float best0 = __builtin_inff(), float2 *pairs = nullptr)
 {
-    q[lane] = 1.0f / (1.0f + det_expf(-(c4 * w[lane])));
-    q[lane + 64] = 1.0f / (1.0f + det_expf(-(c4 * w[lane + 64])));
+    {
+        const float q0 = 1.0f / (1.0f + det_expf(-(c4 * w[lane]))), q1 = 1.0f / (1.0f + det_expf(-(c4 * w[lane + 64])));
+        q[lane] = q0;
+        q[lane + 64] = q1;
+        if (pairs) {
+            pairs[lane] = make_float2(1.0f, q1);                  // chain 0: sum of q over the parity part
+            pairs[64 + lane] = make_float2(1.0f, w[lane + 64]);    // chain 1: sum of |y'| over the parity part
+            pairs[128 + lane] = make_float2(1.0f, q0);            // chain 2: sum of q over the MRB
+            pairs[192 + lane] = make_float2(1.0f - q0, 0.0f);     // chain 3: product of 1 - q over the MRB
+        }
+    }
     wave_fence();
     // sequential (ascending position) means / product, as the oracle defines them: four dependent chains of 64 steps.  Lanes 0..3
     // run one chain each with ONE fused multiply-add per step -- acc * 1 + x is the sum, acc * x + 0 the product, both rounded
     // once like the plain operations (-ffp-contract=off does not touch an explicit fma) -- instead of every lane running all four.
     float a1, aw, at, spl;
-    {
+    if (pairs) {
+        const float2 *const src = pairs + 64 * (lane & 3);
+        float acc = (lane & 3) == 3 ? 1.0f : 0.0f;
+#pragma unroll 8
+        for (int p = 0; p < 64; ++p) {
+            const float2 t = src[p];
+            acc = __builtin_fmaf(acc, t.x, t.y);
+        }
+        a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
+        aw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 1));
+        at = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 2));
+        spl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 3));
+    } else {
         const int ch = lane & 3;
         const float *src = ch == 0 ? q + 64 : (ch == 1 ? w + 64 : q);
         const bool prod = ch == 3;
@@ -250,14 +273,22 @@ __device__ __forceinline__ bool pb_success_q(u64 D, float w1, const float *qpar,
     return p_suc > (float)F.p_t_suc;      // (pb_testing.py:145: TensorFlow compares the float32 tensor with the double cast TO float32)
 }
 
+// (D differs from lane to lane here: the factor is picked bitwise -- bit -> 0 / -1 by a signed field extract of the word's
+//  half, then (y & m) | (x & ~m): three 32-bit instructions a position where (D >> p) & 1 compiled to a 64-bit shift, a 64-bit
+//  compare and a select, five)
 __device__ __forceinline__ bool pb_success(u64 D, float w1, const float2 *tq, const PbFrame &F)
 {
     const float ratio = (1.0f - w1) / w1;
     float prod = 1.0f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int dw = (int)(unsigned)(h ? D >> 32 : D);
 #pragma unroll 8
-    for (int p = 0; p < 64; ++p) {
-        const float2 t = tq[p];
-        prod = prod * (((D >> p) & 1) ? t.y : t.x);
+        for (int u = 0; u < 32; ++u) {
+            const float2 t = tq[32 * h + u];
+            const int m = __builtin_amdgcn_sbfe(dw, u, 1);
+            prod = prod * __int_as_float((__float_as_int(t.y) & m) | (__float_as_int(t.x) & ~m));
+        }
     }
     const float p_suc = 1.0f / (1.0f + ratio / prod);
     return p_suc > (float)F.p_t_suc;      // (pb_testing.py:145: TensorFlow compares the float32 tensor with the double cast TO float32)
@@ -362,7 +393,10 @@ struct PbSinglesLds {
     SearchLdsLean s;     // no byte LUTs: the kernel evaluates two candidates per frame and lane, and it answers to occupancy
     double cdfA[65], cdfH[65];
     float q[128];
-    float2 tq[64];
+    union {
+        float2 pairs[4][64];      // pb_frame_setup's chain operands ...
+        float2 tq[64];            // ... then the success rule's factors
+    };
 };
 
 // (one wavefront per workgroup, 3.4 KiB of LDS each: the register count decides how many are resident.  With the searches' 8 KiB
@@ -407,8 +441,9 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
         }
         PBS_STAMP(0);
         const float best0 = tep_cost_direct_uniform(L.w, 0.0f, S.d0, lane);
-        const PbFrame Fr = pb_frame_setup(L.w, W.q, W.cdfA, P.c4, P.order, P.nmax, lane, best0);
+        const PbFrame Fr = pb_frame_setup(L.w, W.q, W.cdfA, P.c4, P.order, P.nmax, lane, best0, &W.pairs[0][0]);
         PBS_STAMP(1);
+        wave_fence();
         pb_success_terms(W.q, W.tq, lane);
         wave_fence();
         // lane l <-> TEP {63 - l}, visit index l; valid while its weight is below the smallest weight-2 sum
