@@ -399,10 +399,12 @@ struct PbSinglesLds {
     };
 };
 
-// (one wavefront per workgroup, 3.4 KiB of LDS each: the register count decides how many are resident.  With the searches' 8 KiB
+// (seven wavefronts per SIMD asked of the register allocator: 72 VGPRs, no scratch -- with the loads of a frame's start issued
+//  together the kernel took 81 VGPRs and five per SIMD, 89 us instead of 84; at seven 80 us; at eight, 64 VGPRs + 9 spilled, 81 us)
+// (one wavefront per workgroup, 4.8 KiB of LDS each: the register count decides how many are resident.  With the searches' 8 KiB
 //  of LUTs it was 11.2 KiB and 14 per CU; padded to 10 per CU the kernel took 130 instead of 98 us per 33 k frames.)
 template <bool PROF>
-__global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict__ y, const int *__restrict__ index,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void pb_singles_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                          const int *__restrict__ count, long long F,
                                                          const unsigned char *__restrict__ perm_in,
                                                          const u64 *__restrict__ parity_in, PbParams P, int mode,
@@ -417,28 +419,39 @@ __global__ __launch_bounds__(64) void pb_singles_kernel(const float *__restrict_
     const int lane = threadIdx.x;
     SearchLdsLean &L = W.s;
     long long nframes = F;
-    if (count) { const long long c = *count; nframes = c < F ? c : F; }
     const long long wave = blockIdx.x;
     if (mode == 2) {   // every frame to the list replay, in frame order
+        if (count) { const long long c = *count; nframes = c < F ? c : F; }
         for (long long f = wave * 64 + lane; f < nframes; f += (long long)gridDim.x * 64) listB[f] = (int)f;
         if (wave == 0 && lane == 0) ctl[kPbCtlLenB] = (int)nframes;
         return;
     }
-    W.cdfH[lane] = cdf_half[lane];
-    if (lane == 0) W.cdfH[64] = cdf_half[64];
-    wave_fence();
-    for (long long f = wave; f < nframes; f += gridDim.x) {
-        const long long src = index ? index[f] : f;
-        SearchFrame S;
-        if constexpr (PROF) {
-            int o1 = perm_in[f * 128 + lane], o2 = perm_in[f * 128 + 64 + lane];
-            u64 Pr = parity_in[f * 64 + lane];
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(o1), "+v"(o2), "+v"(Pr));
-            PBS_STAMP(5);
-            S = search_prepare_regs<false>(L, y, src, o1, o2, Pr, lane);
-        } else {
-            S = search_prepare<false>(L, y, src, perm_in, parity_in, f, lane);
+    // A wavefront serves one frame (two for a few) and half of its life used to be the chain count -> frame number -> permutation
+    // and P' -> y (in-kernel stamps, round 4): every load that does not depend on another is now issued before the first
+    // is waited for -- the frame's operands are read for f < F (the buffers hold F frames) and dropped if the count says less.
+    // (The wave-uniform words -- frame number, count -- go through VECTOR loads, an opaque zero in the address: a scalar load is
+    //  waited for where it is issued once its result meets a branch, and three of them in a row were three round trips.)
+    int vz = 0;
+    asm volatile("" : "+v"(vz));
+    for (long long f = wave; f < nframes; f += gridDim.x) {      // (nframes = F until the first frame's loads are out)
+        int o1 = perm_in[f * 128 + lane], o2 = perm_in[f * 128 + 64 + lane];
+        u64 Pr = parity_in[f * 64 + lane];
+        int srcv = (int)f;
+        if (index) srcv = index[f + vz];
+        if (f == wave) {
+            const double ch = cdf_half[lane], ch64 = cdf_half[64 + vz];
+            int cv = 0x7FFFFFFF;
+            if (count) cv = count[vz];
+            W.cdfH[lane] = ch;
+            if (lane == 0) W.cdfH[64] = ch64;
+            const long long c = __builtin_amdgcn_readfirstlane(cv);
+            nframes = c < F ? c : F;
+            wave_fence();
         }
+        if (f >= nframes) break;
+        const long long src = __builtin_amdgcn_readfirstlane(srcv);
+        if constexpr (PROF) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(o1), "+v"(o2), "+v"(Pr)); PBS_STAMP(5); }
+        const SearchFrame S = search_prepare_regs<false>(L, y, src, o1, o2, Pr, lane);
         PBS_STAMP(0);
         const float best0 = tep_cost_direct_uniform(L.w, 0.0f, S.d0, lane);
         const PbFrame Fr = pb_frame_setup(L.w, W.q, W.cdfA, P.c4, P.order, P.nmax, lane, best0, &W.pairs[0][0]);
