@@ -1871,13 +1871,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
     const int lane0 = threadIdx.x;
     const int sub = blockIdx.x & (kPbSub - 1);
-    const int len = ctl[kPbCtlLenA + kPbCtlLine * sub];
+    // (the sub-list's length and this workgroup's entry of it are asked for together -- entry k0 < sub_cap exists whatever the
+    //  length says --, through vector loads: a scalar load whose result meets a branch is waited for where it is issued)
+    int vz = 0;
+    asm volatile("" : "+v"(vz));
+    const int k0 = blockIdx.x >> 4;
+    const int lenv = ctl[kPbCtlLenA + kPbCtlLine * sub + vz], f0v = listA[sub * sub_cap + k0 + vz];
+    const int len = __builtin_amdgcn_readfirstlane(lenv);
     const int nall = P.order > 2 ? kPbTabSize : (P.order > 1 ? kPbTriples0 : kPbPairs0);      // TEPs of weight 1..order
     // TEPs after which a search may leave for the workgroup kernel: the fewer frames search, the sooner (a lone wavefront
     // takes ~30 us per chunk of ~400 TEPs, the workgroup ~12 us per chunk of ~2700; the schedule and its measurements: launch_pb)
     const int budget0 = len < 128 ? P.budget_s : (len < 448 ? P.budget_m : (len < 1400 ? P.budget : (len < 3000 ? P.budget_l : P.budget_xl)));
     bool have_cdfh = false;
-    for (int k = blockIdx.x >> 4; k < len; k += gridDim.x >> 4) {
+    for (int k = k0; k < len; k += gridDim.x >> 4) {
         // (an opaque copy of the lane number per frame: otherwise every lane-dependent constant of the frame's code -- item
         //  geometry, the rank sort's tie masks -- is hoisted out of this loop, kept in registers for the whole kernel and spilled)
         int lane = lane0;
@@ -1900,7 +1906,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
         const bool tail_rule = len * kPbSub > P.late_min && len < P.late_maxlen;
         const int tail_budget = budget0 / P.late_div;
         const long long tail_slots = 4096ll * P.late_pct;       // (256 CUs x 16 wavefronts of this kernel, in per cent)
-        const long long f = listA[sub * sub_cap + k];
+        const long long f = k == k0 ? __builtin_amdgcn_readfirstlane(f0v) : listA[sub * sub_cap + k];
         // ---- per-frame set-up: ONE wide load of the record pb_singles_kernel wrote (|y'|, P', the CDF table, the permutation: 356
         // words, copied into LDS as they are), the frame's scalars by scalar loads; derived here: the cost-bound table, the
         // success-rule factors
