@@ -2077,16 +2077,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
 // ---------------------------------------------------------------------------------------
 constexpr int kCoopCap = 4096;        // keys of a chunk, all wavefronts together
 constexpr int kCoopMaxCand = 64;
-constexpr int kCoopWaveKeys = 512;    // keys of a chunk from one wavefront (a sixteenth of the items: 256 +- 10 % when the chunk is full)
-constexpr int kPbCoopW = 16;          // wavefronts per frame
-constexpr int kPbCoopGrid = 256;      // workgroups (frames are handed out by ticket)
+// Wavefronts per frame: 16 (one frame per CU) or 8 (two).  Measured with 8 (round 4), workgroup kernel per
+// launch / PB kernels per search call: 2.5 dB 120 -> 151 us / 0.426 -> 0.451 ms (the launch is its longest search, and a chunk
+// takes eight wavefronts 1.25 x as long), 2.0 dB 270 -> 200 us / 0.945 -> 0.905 ms (throughput-bound: ~1900 searches),
+// 1.5 dB 1.89 -> 1.89 ms, 1.0 dB 245 -> 252 us / 3.75 -> 3.74 ms (its tail again), 3.0 / 3.5 dB 0.287 -> 0.292 / 0.177 -> 0.186 ms.
+constexpr int kPbCoopW = 16;
+constexpr int kPbCoopGrid = 256 * 16 / kPbCoopW;      // workgroups (frames are handed out by ticket): what the chip holds at once
 
 template <int NW>
 struct __attribute__((aligned(16))) PbCoopLds {
     static constexpr int NI = 32 / NW;                    // items per lane
+    static constexpr int WK = 2 * kCoopCap / NW;          // keys of a chunk from one wavefront (an NW-th of the items +- 10 % when the chunk is full: half of this)
     PbWaveLds<kPbWaveCap> one;        // the frame's tables (tail, P, w, tq, cdf); the rest of it is wavefront 0's when it works alone
     u64 keys[kCoopCap];
-    unsigned short slist[NW][kCoopWaveKeys];              // a wavefront's keys that the cost bound could not rule out
+    unsigned short slist[NW][WK];              // a wavefront's keys that the cost bound could not rule out
     uint4 desc[NW][64];                                    // a wavefront's items with members in the chunk (emission)
     u64 ck[kCoopMaxCand], rk[kCoopMaxCand];
     float cc[kCoopMaxCand], rc[kCoopMaxCand];
@@ -2156,9 +2160,14 @@ __device__ __forceinline__ int coop_min(CoopRed<NW> &R, int x)
 template <int NW>
 __device__ __forceinline__ void coop_item(int v, int j, int lane, int &q, int &l)
 {
-    static_assert(NW == 16, "the dealing is written for sixteen wavefronts");
-    q = 16 * j + (lane >> 2);
-    l = ((13 * (v - 3 * q)) & 15) + 16 * (lane & 3);        // 5 l = v - 3 q (mod 16), 5 * 13 = 1
+    static_assert(NW == 16 || NW == 8, "the dealing is written for sixteen or eight wavefronts");
+    if constexpr (NW == 16) {
+        q = 16 * j + (lane >> 2);
+        l = ((13 * (v - 3 * q)) & 15) + 16 * (lane & 3);        // 5 l = v - 3 q (mod 16), 5 * 13 = 1
+    } else {            // (5 l + 3 q) mod 8: eight items of every row, four rows of a lane
+        q = 8 * j + (lane >> 3);
+        l = ((5 * (v - 3 * q)) & 7) + 8 * (lane & 7);           // 5 l = v - 3 q (mod 8), 5 * 5 = 1
+    }
 }
 
 // A wavefront's items in registers: item j of this lane is (row q, lane l) = coop_item(v, j, lane); sb = the sum of its fixed
@@ -2247,7 +2256,7 @@ __device__ __forceinline__ int coop_next_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
         slot = R.seq & 7;
         {
             const int cw = wave_add_i32(c);
-            tot = coop_sum<NW>(R, cw > kCoopWaveKeys ? cw + (1 << 24) : cw);     // (a wavefront scans its own keys: at most kCoopWaveKeys)
+            tot = coop_sum<NW>(R, cw > PbCoopLds<NW>::WK ? cw + (1 << 24) : cw);     // (a wavefront scans its own keys: at most WK)
         }
         PBC_STAMP(kPcWBarrier);
         last_ok = false;
@@ -2346,7 +2355,7 @@ template <int NW, bool PROF>
 __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R, const PbParams &P, const PbFrame &Fr, u64 d0, int n, int kbase, int kcount,
                                                float mn, float mx, int lane, int wave, PbwState &S, int &stop, int &ntep, PbcProf &Q)
 {
-    constexpr int CAP = kPbWaveCap, PER = kCoopWaveKeys / 64;
+    constexpr int CAP = kPbWaveCap, PER = PbCoopLds<NW>::WK / 64;
     const PbWaveLds<CAP> &T0 = L.one;
     if (S.nlive <= 1) return -1;
     const float best0 = S.best;
@@ -2439,7 +2448,7 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
         }
     }
     PBC_STAMP(kPcSSurv);
-    // the exchange: frontier growth and the pops that shrink it (per wavefront |growth| <= 2 * 512 < 2^12), the smallest firing sum
+    // the exchange: frontier growth and the pops that shrink it (per wavefront |growth| <= 2 * WK <= 2^11), the smallest firing sum
     int negtot, deltot;
     unsigned sF;
     {
@@ -2614,7 +2623,7 @@ __device__ __forceinline__ void coop_solo_range(PbCoopLds<NW> &L)
 }
 
 template <int NW, bool PROF>
-__global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const double *__restrict__ cdf_half, int *__restrict__ ctl, int *__restrict__ listB,
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) void pb_coop_kernel(PbParams P, const double *__restrict__ cdf_half, int *__restrict__ ctl, int *__restrict__ listB,
                                                           const unsigned *__restrict__ carry, PbOut O, unsigned long long *__restrict__ prof_out)
 {
     // (dynamic LDS: a hipGraph kernel node with more than 64 KiB of STATIC LDS aborts at replay on ROCm 7.2; the size is
@@ -2626,7 +2635,6 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
     if constexpr (PROF) { if (threadIdx.x == 0) for (int k = 0; k < kPcSlots; ++k) Q.pc[k] = 0; Q.last = __builtin_amdgcn_s_memtime(); }
     PbCoopLds<NW> &L = *reinterpret_cast<PbCoopLds<NW> *>(pb_coop_lds);
     constexpr int NI = 32 / NW;
-    static_assert(64 * NW >= 64 + kPbRecPrefix, "wavefronts 1.. copy a record's tables in one go");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // list C: ticket t < nfar -> record t (the searches expected to run far), the others -> record kPbCoopHalf + (t - nfar)
     const int lenc = ctl[kPbCtlLenC], lenc2 = ctl[kPbCtlLenC2];
@@ -2648,7 +2656,8 @@ __global__ __launch_bounds__(64 * NW) void pb_coop_kernel(PbParams P, const doub
         if (tid == 0) { next_tk = atomicAdd(&ctl[kPbCtlTicketC], 1); L.ncand[0] = 0; L.ncand[1] = 0; }
         const unsigned *rec = carry + (long long)(tk < nfar ? tk : kPbCoopHalf + (tk - nfar)) * kPbRecWords;
         // the frame's tables: one load per thread (wavefront 0 may still be writing the previous frame's codeword out)
-        if (tid >= 64 && tid < 64 + kPbRecPrefix) reinterpret_cast<unsigned *>(&L.one)[tid - 64] = rec[tid - 64];
+        if (tid >= 64)
+            for (int i = tid - 64; i < kPbRecPrefix; i += 64 * NW - 64) reinterpret_cast<unsigned *>(&L.one)[i] = rec[i];
         const PbCarry &c = *reinterpret_cast<const PbCarry *>(rec + kPbRecScalars);
         unsigned po = wave == 0 ? rec[kPbRecPerm + (lane >> 2)] : 0u, po2 = wave == 0 ? rec[kPbRecPerm + 16 + (lane >> 2)] : 0u;      // (the permutation, for the codeword at the end: in flight from here)
         PbFrame Fr = c.fr;
@@ -2972,7 +2981,7 @@ ldpc_pb_tuning pb_default_tuning()
 int pb_ctx_init(ldpc_ctx *ctx)
 {
     state(ctx)->pb_tuning = pb_default_tuning();
-    static_assert(sizeof(PbCoopLds<kPbCoopW>) <= 160 * 1024, "one workgroup per CU");
+    static_assert(sizeof(PbCoopLds<kPbCoopW>) * (16 / kPbCoopW) <= 160 * 1024, "16 wavefronts of this kernel per CU");
     LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_coop_kernel<kPbCoopW, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(PbCoopLds<kPbCoopW>)));
     LDPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_coop_kernel<kPbCoopW, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
