@@ -168,6 +168,18 @@ def test_workgroup_kernel_dealing_is_a_bijection():
                 assert (q, l) not in seen
                 seen.add((q, l))
     assert len(seen) == 32 * 64
+    # the eight-wavefront form of the template (two frames per CU; measured, not the product setting): row q = 8 j + lane / 8,
+    # lane l = (5 (v - 3 q) mod 8) + 8 (lane mod 8), the items with (5 l + 3 q) mod 8 = v
+    seen = set()
+    for v in range(8):
+        for j in range(4):
+            for lane in range(64):
+                q = 8 * j + (lane >> 3)
+                l = ((5 * (v - 3 * q)) & 7) + 8 * (lane & 7)
+                assert (5 * l + 3 * q) % 8 == v
+                assert (q, l) not in seen
+                seen.add((q, l))
+    assert len(seen) == 32 * 64
 
 
 def test_workgroup_kernel_dealing_balances_a_chunk(np_code):
