@@ -2075,7 +2075,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pb
 // one entry) is redone by wavefront 0 alone with the single-wavefront code above (sorted path, sub-chunks of <= 512 keys up
 // to the same bound), then the co-operation resumes.  Frames arrive from pb_wave_kernel with their search state and cursors.
 // ---------------------------------------------------------------------------------------
-constexpr int kCoopCap = 4096;        // keys of a chunk, all wavefronts together
+constexpr int kCoopCap = 4096;        // keys of a chunk, all wavefronts together (8192 with a target of 6144 measured in round 4: fewer, longer
+                                      // chunks -- per search call 0.428 -> 0.411 ms at 2.5 dB, 0.926 -> 0.941 at 2.0 dB, 3.75 -> 3.84 at 1.0 dB)
 constexpr int kCoopMaxCand = 64;
 // Wavefronts per frame: 16 (one frame per CU) or 8 (two).  Measured with 8 (round 4), workgroup kernel per
 // launch / PB kernels per search call: 2.5 dB 120 -> 151 us / 0.426 -> 0.451 ms (the launch is its longest search, and a chunk
