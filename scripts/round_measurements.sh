@@ -12,6 +12,9 @@ b pb3 --workload nms10_pb3
 b pb3_snr1.0 --workload nms10_pb3 --snr 1.0 --steps 40 --warmup 4
 b surface --workload surface_nms --steps 6 --warmup 2
 timeout -k 10 500 python scripts/snr_sweep.py --snr 1.0 3.5 6 --frames 1048576 --osd pb --order 3 --cpu-check --cpu-seconds 8 > $P/snr_sweep_pb3_1M.jsonl 2> $O/${RND}_sweep_pb3.err; echo "[sweep pb3] rc=$?"
+# (the same sweep without the CPU check: between two points the host then does nothing for 8 s with 16 threads, and the points that
+#  follow a check read 5-15 % lower -- timing from this file, FER judgement from the one above)
+timeout -k 10 300 python scripts/snr_sweep.py --snr 1.0 3.5 6 --frames 1048576 --osd pb --order 3 > $P/snr_sweep_pb3_1M_timing.jsonl 2> $O/${RND}_sweep_pb3_timing.err; echo "[sweep pb3 timing] rc=$?"
 timeout -k 10 300 python scripts/snr_sweep.py --snr 1.0 3.5 6 --frames 1048576 --osd conv --order 2 > $P/snr_sweep_conv2_1M.jsonl 2> $O/${RND}_sweep_conv2.err; echo "[sweep conv2] rc=$?"
 timeout -k 10 300 python scripts/snr_sweep.py --snr 2.0 3.0 3 --frames 4194304 --batch 16384 --osd pb --order 3 --stop-errors 100 > $P/snr_sweep_pb3_stop100.jsonl 2> $O/${RND}_sweep_pb3_stop100.err; echo "[sweep stop] rc=$?"
 python - <<PY
