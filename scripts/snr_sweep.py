@@ -145,6 +145,7 @@ def main():
         sizes = [min(args.batch, mine - k * args.batch) for k in range(max_batches) if mine - k * args.batch > 0]
         ahead = [produce(sizes[0], snr, dstreams[0])] if sizes else []
         taken = [0]
+        pool = {}      # (stream number, batch size) -> pipeline object of this point: its output buffers are made once, not per batch
 
         def decode_batch(B, snr=snr):
             y, lab, ev = ahead.pop(0)
@@ -155,10 +156,15 @@ def main():
             assert y.shape[0] == B
             with torch.cuda.stream(st):
                 st.wait_event(ev)
-                pipe = BatchPipeline(dec, B, args.iters, alpha, osd_order=args.order, osd_algo=ALGOS[args.osd], snr_db=snr,
-                                     want_soft=False, keep_front=False).bind(y, lab)
-                pipe.run()
-                c = pipe.counters()
+                key = ((taken[0] - 1) % len(dstreams), B)
+                pipe = pool.get(key)
+                if pipe is None:
+                    pipe = pool[key] = BatchPipeline(dec, B, args.iters, alpha, osd_order=args.order, osd_algo=ALGOS[args.osd], snr_db=snr,
+                                                     want_soft=False, keep_front=False)
+                else:
+                    pipe.reset_counters()
+                pipe.bind(y, lab).run()
+                c = pipe.counters().clone()      # (the object's own counters are zeroed for its next batch on this stream)
                 done_ev = torch.cuda.Event()
                 done_ev.record(st)
             if st is not main_stream:
