@@ -186,6 +186,26 @@ def test_pb_workgroup_kernel_ties(dec, quant):
         dec.set_pb_tuning(**prev)
 
 
+@pytest.mark.parametrize("tuning", [dict(budget_s=64, budget_m=64, budget=64), dict(budget_s=700, budget_m=700, budget=700),
+                                    dict(late_pct=100000, late_div=64, late_min=0)])
+def test_pb_ties_under_schedules(dec, tuning):
+    """Equal sums against reference keys inside the workgroup kernel's sort-free pass (ordered by the visit comparator since
+    round 4, not handed to one wavefront): quantised channel values, searches handed on after 64 / 700 TEPs and by the tail
+    rule from the first chunk on.  (tests/tools/pb_tie_stress.py: the long form, 8640 decodes.)"""
+    prev = dec.set_pb_tuning(**tuning)
+    try:
+        for quant, snr, order in ((256.0, 1.0, 3), (65536.0, 2.0, 3), (64.0, 1.5, 2)):
+            rng = np.random.default_rng(int(quant) + 7)
+            y, cw = np_oracle.make_frames(dec.code.G, snr, 300, rng)
+            y = (np.round(y * quant) / quant).astype(np.float32)
+            soft = c_oracle.nms(dec.code.H, y, 10, ALPHA0)
+            _, fail, _ = c_oracle.evaluate(dec.code.H, soft, cw)
+            idx = np.flatnonzero(fail)[:64]
+            _check(dec, y[idx], cw[idx], order, snr, None)
+    finally:
+        dec.set_pb_tuning(**prev)
+
+
 @pytest.mark.parametrize("snr,B", [(2.5, 131072), (1.0, 131072)])
 def test_pb_full_size_properties(dec, snr, B):
     """BASELINE config 5 sizes: size-independent properties of PB-OSD order 3 on the NMS failures of a full batch.
