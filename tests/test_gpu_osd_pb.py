@@ -206,7 +206,7 @@ def test_pb_ties_under_schedules(dec, tuning):
         dec.set_pb_tuning(**prev)
 
 
-@pytest.mark.parametrize("snr,B", [(2.5, 131072), (1.0, 131072)])
+@pytest.mark.parametrize("snr,B", [(2.5, 131072), (1.0, 131072), (1.75, 131072)])
 def test_pb_full_size_properties(dec, snr, B):
     """BASELINE config 5 sizes: size-independent properties of PB-OSD order 3 on the NMS failures of a full batch.
     The chunk bounds, the hand-over to the workgroup kernel and the order of the keys inside a chunk depend on the batch
