@@ -583,7 +583,10 @@ def run_rank(args):
     assert frames_total == B * args.steps * world, (frames_total, B, args.steps, world)
     value = frames_total / elapsed
     res = {
-        "metric": "decoded frames/sec + FER, (128,64) LDPC NMS-10+OSD-2 @ 2.5 dB",
+        # (BASELINE.json's metric, word for word, on the workload it is quoted on; the other workloads say what they decode)
+        "metric": "decoded frames/sec + FER, (128,64) LDPC %s @ %s dB" % (
+            {"nms10": "NMS-10", "nms10_osd0": "NMS-10+OSD-0", "nms10_osd2": "NMS-10+OSD-2", "nms10_fs2": "NMS-10+FS-OSD-2",
+             "nms10_pb3": "NMS-10+PB-OSD-3"}[args.workload], ("%.2f" % args.snr).rstrip("0").rstrip(".") if args.snr != 2.5 else "2.5"),
         "timed_region": timed_region,
         # (machine-readable form of the above -- with parallel branches ms_per_step is a throughput reciprocal, not
         #  a step latency; `--graph-branches 1` times one chain)
