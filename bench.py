@@ -443,7 +443,7 @@ def run_rank(args):
     for i in range(nb):                                # distinct batches, each with its own buffers
         y, labels = make_frames(dec, B, seed=20241020 + rank + 1000 * i, snr_db=args.snr)
         pipes.append(BatchPipeline(dec, B, T_ITERS, alpha, osd_order=order, osd_algo=algo, snr_db=args.snr,
-                                   keep_front=args.osd_route == "front+search" or algo != 0 or order != 2).bind(y, labels))
+                                   keep_front=args.osd_route == "front+search").bind(y, labels))
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(1, max(1, args.streams))]
 
     def run_step(k, slot=-1):
@@ -626,12 +626,17 @@ def run_rank(args):
                 kern["osd_front_kernel"] = (float(tm[:, 1].mean()), (512 + 640) * f_per_step)
                 sname = {1: "osd_fs_kernel", 2: "pb_osd (singles + chunk + workgroup kernels)"}.get(algo, "osd_search2r_kernel" if order == 2 else "osd_search_kernel")
                 kern[sname] = (float(tm[:, 2].mean()), (1152 + 24) * f_per_step)
-            else:                        # ldpc_osd_decode: one duration (conventional order 2: ONE kernel, osd_fused2r_kernel)
-                kern["osd_fused2r_kernel (front end + order-2 scan)"] = (float(tm[:, 2].mean()), OSD_BYTES_PER_FRAME * f_per_step)
+            else:                        # ldpc_osd_decode: one duration (conventional order 2: ONE kernel, osd_fused2r_kernel;
+                #                          PB-OSD: the front end inside the singles kernel; others: front end into the workspace + search)
+                dname = {1: "osd_front_kernel + osd_fs_kernel (through the workspace)",
+                         2: "osd_front_kernel + pb_osd (through the workspace)"}.get(
+                             algo, "osd_fused2r_kernel (front end + order-2 scan)" if order == 2 else "osd_front_kernel + osd_search_kernel (through the workspace)")
+                kern[dname] = (float(tm[:, 2].mean()), OSD_BYTES_PER_FRAME * f_per_step)
         name = max(kern, key=lambda k: kern[k][0])
         ms, nbytes = kern[name]
         achieved = nbytes / (ms * 1e-3) / 1e9
-        traffic, issue, prof_path = pmc_profile(name if name.startswith("pb_osd") else name.split(" ")[0], args.workload if args.snr == SNR_DB else f"{args.workload}_snr{args.snr}", B)
+        traffic, issue, prof_path = pmc_profile(name if name.startswith("pb_osd") else name.split(" ")[0],
+                                                  args.workload + ("_fused" if args.osd_route == "decode" and order is not None else "") + ("" if args.snr == SNR_DB else f"_snr{args.snr}"), B)
         res["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_issue_ratio": issue, "pmc_profile": prof_path,
                            "avg_launch_ms": ms, "timed_launches": len(timed_slots), "timed_in": "separate event-bracketed pass after the timed region",

@@ -200,7 +200,8 @@ typedef struct ldpc_osd_params {
     int32_t fs_reference_quirk; /* 1: keep optimal_codeword un-updated on a tau_e hit (fs_testing.py:145) */
     int32_t reserved;    /* 0; cross-check switches: bit 0 = conventional order 2 through the table-driven scan instead of
                             the register-resident kernels, bit 3 = the register-resident kernel with v_readlane
-                            pairing instead of the rotation-paired persistent one; PB-OSD: bit 1 = every frame
+                            pairing instead of the rotation-paired persistent one; PB-OSD: bit 0 = ldpc_osd_decode runs the front
+                            end inside the first PB kernel (no workspace traffic; 4-5 % slower), bit 1 = every frame
                             through the sorted-chunk kernel from its first TEP, bit 2 = every frame through the
                             literal list replay                                                               */
     void *d_aux;         /* optional DEVICE [F][4] i32, PB-OSD statistics per frame: {frontier comparisons

@@ -46,7 +46,7 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, h) for h in ("ldpc_internal.h", "ldpc_wave.h", "ldpc_search.h", "ldpc_osd_state.h")]
+    headers = [os.path.join(CSRC, h) for h in ("ldpc_internal.h", "ldpc_wave.h", "ldpc_search.h", "ldpc_front.h", "ldpc_osd_state.h")]
     headers.append(os.path.join(HERE, "..", "include", "ldpc_osd.h"))
     jobs = []
     for src in SOURCES:

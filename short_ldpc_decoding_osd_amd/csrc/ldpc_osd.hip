@@ -34,6 +34,7 @@
 #include "ldpc_internal.h"
 #include "ldpc_wave.h"
 #include "ldpc_search.h"
+#include "ldpc_front.h"
 #include "ldpc_osd_state.h"
 
 namespace ldpc {
@@ -63,75 +64,8 @@ __global__ __launch_bounds__(256) void osd_ge_kernel(const u64 *__restrict__ row
 }
 
 // ---------------------------------------------------------------------------------------
-// OSD front end
+// OSD front end (the per-frame device code: ldpc_front.h)
 // ---------------------------------------------------------------------------------------
-struct __attribute__((aligned(16))) FrontLds {
-    RankLds rank;            // reliability sort (bucket_ranks, ldpc_wave.h)
-    u64 colbuf[64];          // parity columns in primed order
-    unsigned mask[4];        // 128-bit membership mask of the MRB indices
-    unsigned char pi1[128];  // sorted position -> original bit
-    unsigned char rowsrc[64];
-    unsigned char perm[128]; // primed position -> original bit
-};
-
-struct FrontResult {
-    int o1, o2;   // original bit index of primed positions lane and 64 + lane
-    u64 Prow;     // row `lane` of P'
-    int ns;       // recorded column exchanges (-1: rank-deficient)
-};
-
-
-// sort + column gather + elimination + bookkeeping of one frame (one wavefront); results in registers
-// (a1 / a2: the magnitude bits of y[lane] / y[64 + lane])
-__device__ __forceinline__ FrontResult front_device_vals(FrontLds &L, unsigned a1, unsigned a2, const u64 *__restrict__ Gcols, int lane)
-{
-    // ---- reliability sort: rank of each |y| in descending order, ties -> lower index ------
-    // sort key = (|y| bits, 127 - index) as one 64-bit integer: "u before v" <=> key_u > key_v (bucket_ranks)
-    const float bs = bucket_scale(a1, a2);
-    int r1, r2;
-    bucket_ranks(L.rank, ((u64)a1 << 32) | (unsigned)(127 - lane), ((u64)a2 << 32) | (unsigned)(63 - lane), bucket_of(a1, bs),
-                 bucket_of(a2, bs), lane, r1, r2);
-    L.pi1[r1] = (unsigned char)lane;
-    L.pi1[r2] = (unsigned char)(lane + 64);
-    if (lane < 4) L.mask[lane] = 0;
-    wave_fence();
-    // ---- G with columns in sorted order, column-major ------------------------------------
-    u64 C1 = Gcols[L.pi1[lane]];
-    u64 C2 = Gcols[L.pi1[lane + 64]];
-    int rho = lane, idx1 = lane, idx2 = lane + 64;
-    const int ns = ge_columns(C1, C2, rho, idx1, idx2, lane, nullptr);
-    // ---- identify_mrb bookkeeping (pb_testing.py:276-304) --------------------------------
-    // (no column exchange -- the 64 most reliable columns were independent: a quarter of the frames -- leaves every index
-    //  where the sort put it: the ranks are the lane numbers and the membership mask is not needed)
-    int rankM = lane, rankL = lane;
-    if (ns != 0) {
-        atomicOr(&L.mask[idx1 >> 5], 1u << (idx1 & 31));
-        wave_fence();
-        const unsigned m[4] = {L.mask[0], L.mask[1], L.mask[2], L.mask[3]};
-        rankM = below_mask(m, idx1);         // new MRB position of slot `lane`
-        rankL = idx2 - below_mask(m, idx2);  // new parity column of slot `lane`
-    }
-    L.perm[rankM] = L.pi1[idx1];
-    L.perm[64 + rankL] = L.pi1[idx2];
-    L.colbuf[rankL] = C2;
-    L.rowsrc[rankM] = (unsigned char)rho;          // pivot of MRB slot `lane` is physical row rho
-    wave_fence();
-    const u64 R = transpose64(L.colbuf[lane], lane);   // lane = physical row, bit = parity column
-    FrontResult res;
-    res.Prow = shfl64(R, L.rowsrc[lane]);
-    res.o1 = L.perm[lane];
-    res.o2 = L.perm[64 + lane];
-    res.ns = ns;
-    wave_fence();
-    return res;
-}
-
-__device__ __forceinline__ FrontResult front_device(FrontLds &L, const float *__restrict__ y, long long src,
-                                                    const u64 *__restrict__ Gcols, int lane)
-{
-    return front_device_vals(L, __float_as_uint(y[src * 128 + lane]) & 0x7FFFFFFFu, __float_as_uint(y[src * 128 + 64 + lane]) & 0x7FFFFFFFu, Gcols, lane);
-}
-
 __global__ __launch_bounds__(64) void osd_front_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                         const int *__restrict__ count, long long F,
                                                         const u64 *__restrict__ Gcols,
@@ -1098,6 +1032,13 @@ int osd_decode_counted(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, 
         if (counted_by_search) *counted_by_search = cnt;
         return LDPC_OK;
     }
+    // PB-OSD with reserved bit 0: the front end runs INSIDE the first PB kernel and nothing goes through a workspace (round 4;
+    // not with bit 2, the list-replay route, which writes no records to set a frame up from).  Measured against the two kernels
+    // (osd_front + pb_singles, per 131 072-frame step): 170 against 164 us at 2.5 dB, 507 against 481 us at 1.0 dB, 58 against 102 MB
+    // and 236 against 400 MB of HBM traffic -- the path is instruction-bound, the traffic was never its limiter: an option, not
+    // the default.
+    if (p->algo == LDPC_OSD_PB && (p->reserved & 5) == 1)
+        return launch_pb(ctx, d_y, d_index, d_count, F, nullptr, nullptr, p, d_cw, d_metric, d_best, d_ntep, s);
     StreamWs *w;
     if ((rc = stream_ws(ctx, s, F, &w))) return rc;
     hipLaunchKernelGGL(osd_front_kernel, dim3((unsigned)(F < 65536 ? F : 65536)), dim3(64), 0, s, d_y, d_index, d_count, (long long)F,

@@ -42,6 +42,7 @@
 #include "ldpc_internal.h"
 #include "ldpc_wave.h"
 #include "ldpc_search.h"
+#include "ldpc_front.h"
 #include "ldpc_osd_state.h"
 
 namespace ldpc {
@@ -389,7 +390,8 @@ __device__ __forceinline__ float wave_incl_min(float v, int) { return wave_incl_
 // stage 1: the weight-1 head of the pop sequence, one frame per wavefront, one TEP per lane
 //   mode 0: normal; 1: every frame straight to list A (block kernel); 2: every frame to list B (list replay)
 // ---------------------------------------------------------------------------------------
-struct PbSinglesLds {
+template <bool FUSED>
+struct PbSinglesLdsT {
     SearchLdsLean s;     // no byte LUTs: the kernel evaluates two candidates per frame and lane, and it answers to occupancy
     double cdfA[65], cdfH[65];
     float q[128];
@@ -398,16 +400,35 @@ struct PbSinglesLds {
         float2 tq[64];            // ... then the success rule's factors
     };
 };
+// FUSED: the OSD front end of the frame runs in this kernel first (ldpc_osd_decode's route: nothing goes through a workspace);
+// its scratch lies under the tables that are filled afterwards, the frame's channel row beside it.
+template <>
+struct PbSinglesLdsT<true> {
+    SearchLdsLean s;
+    double cdfH[65];
+    float yrow[128];
+    union {
+        FrontLds front;
+        struct {
+            double cdfA[65];
+            float q[128];
+            union {
+                float2 pairs[4][64];
+                float2 tq[64];
+            };
+        };
+    };
+};
 
 // (seven wavefronts per SIMD asked of the register allocator: 72 VGPRs, no scratch -- with the loads of a frame's start issued
 //  together the kernel took 81 VGPRs and five per SIMD, 89 us instead of 84; at seven 80 us; at eight, 64 VGPRs + 9 spilled, 81 us)
 // (one wavefront per workgroup, 4.8 KiB of LDS each: the register count decides how many are resident.  With the searches' 8 KiB
 //  of LUTs it was 11.2 KiB and 14 per CU; padded to 10 per CU the kernel took 130 instead of 98 us per 33 k frames.)
-template <bool PROF>
+template <bool PROF, bool FUSED = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void pb_singles_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                          const int *__restrict__ count, long long F,
                                                          const unsigned char *__restrict__ perm_in,
-                                                         const u64 *__restrict__ parity_in, PbParams P, int mode,
+                                                         const u64 *__restrict__ parity_in, const u64 *__restrict__ Gcols, PbParams P, int mode,
                                                          const double *__restrict__ cdf_half,
                                                          int *__restrict__ ctl, int *__restrict__ listA, int *__restrict__ listB, int sub_cap,
                                                          unsigned *__restrict__ recs, PbOut O, unsigned long long *__restrict__ prof_out)
@@ -415,7 +436,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void pb
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 #define PBS_STAMP(k) do { if constexpr (PROF) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); pt[k] += now__ - plast; plast = now__; } } while (0)
-    __shared__ PbSinglesLds W;
+    __shared__ PbSinglesLdsT<FUSED> W;
     const int lane = threadIdx.x;
     SearchLdsLean &L = W.s;
     long long nframes = F;
@@ -434,8 +455,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void pb
     int vz = 0;
     asm volatile("" : "+v"(vz));
     for (long long f = wave; f < nframes; f += gridDim.x) {      // (nframes = F until the first frame's loads are out)
-        int o1 = perm_in[f * 128 + lane], o2 = perm_in[f * 128 + 64 + lane];
-        u64 Pr = parity_in[f * 64 + lane];
+        int o1 = 0, o2 = 0;
+        u64 Pr = 0;
+        if constexpr (!FUSED) { o1 = perm_in[f * 128 + lane]; o2 = perm_in[f * 128 + 64 + lane]; Pr = parity_in[f * 64 + lane]; }
         int srcv = (int)f;
         if (index) srcv = index[f + vz];
         if (f == wave) {
@@ -451,7 +473,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void pb
         if (f >= nframes) break;
         const long long src = __builtin_amdgcn_readfirstlane(srcv);
         if constexpr (PROF) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(o1), "+v"(o2), "+v"(Pr)); PBS_STAMP(5); }
-        const SearchFrame S = search_prepare_regs<false>(L, y, src, o1, o2, Pr, lane);
+        SearchFrame S;
+        if constexpr (FUSED) {
+            // the frame's row as it lies in memory (two coalesced loads), the front end on it, then y' = y[perm] out of LDS
+            const float ya = y[src * 128 + lane], yb = y[src * 128 + 64 + lane];
+            W.yrow[lane] = ya; W.yrow[64 + lane] = yb;
+            const FrontResult fr = front_device_vals(W.front, __float_as_uint(ya) & 0x7FFFFFFFu, __float_as_uint(yb) & 0x7FFFFFFFu, Gcols, lane);
+            wave_fence();
+            S = search_prepare_vals<false>(L, W.yrow[fr.o1], W.yrow[fr.o2], fr.o1, fr.o2, fr.Prow, lane);
+        } else {
+            S = search_prepare_regs<false>(L, y, src, o1, o2, Pr, lane);
+        }
         PBS_STAMP(0);
         const float best0 = tep_cost_direct_uniform(L.w, 0.0f, S.d0, lane);
         const PbFrame Fr = pb_frame_setup(L.w, W.q, W.cdfA, P.c4, P.order, P.nmax, lane, best0, &W.pairs[0][0]);
@@ -2778,9 +2810,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) vo
 // stage 3: literal replay of the frontier list, one frame of list B per wavefront (frames whose sums tie
 // massively, or every frame when the caller asks for this path as a cross-check)
 // ---------------------------------------------------------------------------------------
+// (recs: the singles kernel's records, when the front end ran inside it and left nothing in a workspace: a frame of list B is
+//  then set up from its record -- |y'|, P', the permutation, the hard decisions)
 __global__ __launch_bounds__(256) void pb_seq_kernel(const float *__restrict__ y, const int *__restrict__ index,
                                                      const unsigned char *__restrict__ perm_in,
-                                                     const u64 *__restrict__ parity_in, PbParams P,
+                                                     const u64 *__restrict__ parity_in, const unsigned *__restrict__ recs, PbParams P,
                                                      const double *__restrict__ cdf_half,
                                                      PbEntry *__restrict__ spill_all, long long spill_stride,
                                                      int *__restrict__ ctl, const int *__restrict__ listB, PbOut O)
@@ -2804,8 +2838,24 @@ __global__ __launch_bounds__(256) void pb_seq_kernel(const float *__restrict__ y
         const int tk = __builtin_amdgcn_readfirstlane(fq);
         if (tk >= nlist) break;
         const long long f = listB[tk];
-        const long long src = index ? index[f] : f;
-        const SearchFrame S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+        SearchFrame S;
+        if (recs) {
+            const unsigned *const R = recs + f * kPbR1Words;
+            const PbHead &H = *reinterpret_cast<const PbHead *>(R + kPbR1Head);
+            const unsigned char *const pb = reinterpret_cast<const unsigned char *>(R + kPbR1Perm);
+            S.o1 = pb[lane]; S.o2 = pb[64 + lane];
+            L.perm[lane] = (unsigned char)S.o1; L.perm[lane + 64] = (unsigned char)S.o2;
+            L.w[lane] = __uint_as_float(R[lane]); L.w[lane + 64] = __uint_as_float(R[64 + lane]);
+            L.P[lane] = reinterpret_cast<const u64 *>(R + 128)[lane];
+            if (lane < 2) L.cw[lane] = 0;
+            S.hm = H.hm; S.hp = H.hp; S.d0 = H.d0;
+            wave_fence();
+            build_byte_luts<8>(L.lut, &L.w[64], lane);
+            wave_fence();
+        } else {
+            const long long src = index ? index[f] : f;
+            S = search_prepare(L, y, src, perm_in, parity_in, f, lane);
+        }
         const PbFrame Fr = pb_frame_setup(L.w, B.q, B.cdfA, P.c4, P.order, P.nmax, lane);
         const float spl = Fr.spl, lrb_mean = Fr.lrb_mean;
         const double p_t_suc = Fr.p_t_suc, p_t_pro = Fr.p_t_pro;
@@ -3094,14 +3144,24 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
     const int64_t want = (F + 3) / 4;
     const unsigned g1 = (unsigned)(F < 1 ? 1 : (F < 32768 ? F : 32768));
     static const bool profile_s = getenv("LDPC_PB_PROFILE") != nullptr;
-    if (!profile_s) {
-        hipLaunchKernelGGL(pb_singles_kernel<false>, dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
+    // d_perm == nullptr (ldpc_osd_decode's route): the front end runs inside the singles kernel, nothing goes through a workspace
+    // -- the frames of list B are then set up from the singles records (mode 2, every frame to the list replay, writes none:
+    // the caller keeps the two-kernel route for it)
+    const bool fused_front = d_perm == nullptr;
+    if (fused_front && (mode == 2 || d_parity != nullptr))
+        return fail(LDPC_E_ARG, "PB-OSD: the fused front end needs both front-end buffers absent and is not the list-replay route");
+    const u64 *const Gcols = reinterpret_cast<const u64 *>(ctx->d_Gcols);
+    if (fused_front) {
+        hipLaunchKernelGGL((pb_singles_kernel<false, true>), dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, Gcols, pp, mode,
+                           st->d_cdf_half, w->d_pb_ctl, listA, listB, sub_cap, recs, O, (unsigned long long *)nullptr);
+    } else if (!profile_s) {
+        hipLaunchKernelGGL((pb_singles_kernel<false, false>), dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, Gcols, pp, mode,
                            st->d_cdf_half, w->d_pb_ctl, listA, listB, sub_cap, recs, O, (unsigned long long *)nullptr);
     } else {
         static unsigned long long *d_ps = nullptr;
         if (!d_ps) LDPC_HIP(hipMalloc((void **)&d_ps, sizeof(unsigned long long) * 8));
         LDPC_HIP(hipMemsetAsync(d_ps, 0, sizeof(unsigned long long) * 8, s));
-        hipLaunchKernelGGL(pb_singles_kernel<true>, dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, pp, mode,
+        hipLaunchKernelGGL((pb_singles_kernel<true, false>), dim3(g1), dim3(64), 0, s, d_y, d_index, d_count, (long long)F, d_perm, d_parity, Gcols, pp, mode,
                            st->d_cdf_half, w->d_pb_ctl, listA, listB, sub_cap, recs, O, d_ps);
         unsigned long long h[8];
         LDPC_HIP(hipMemcpyAsync(h, d_ps, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -3164,7 +3224,7 @@ int launch_pb(ldpc_ctx *ctx, const float *d_y, const int32_t *d_index, const int
         fprintf(stderr, "\n");
     }
     const unsigned g3 = (unsigned)(want < kPbSeqBlocks ? (want < 1 ? 1 : want) : kPbSeqBlocks);
-    hipLaunchKernelGGL(pb_seq_kernel, dim3(g3), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, pp, st->d_cdf_half,
+    hipLaunchKernelGGL(pb_seq_kernel, dim3(g3), dim3(256), 0, s, d_y, d_index, d_perm, d_parity, fused_front ? recs : (const unsigned *)nullptr, pp, st->d_cdf_half,
                        reinterpret_cast<PbEntry *>(w->d_pb_spill), (long long)w->pb_spill_stride, w->d_pb_ctl, listB, O);
     LDPC_HIP(hipGetLastError());
     return LDPC_OK;

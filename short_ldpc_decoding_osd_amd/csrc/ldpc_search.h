@@ -102,14 +102,13 @@ struct SearchFrame {
 // (LUTS = false: the caller builds the byte LUTs itself, e.g. spread over the wavefronts of a workgroup)
 // (LDS: SearchLds, or a struct with the same P / w / cw members and no LUTs -- SearchLdsLean -- for a kernel that evaluates a
 //  handful of candidates per frame and is better served by the occupancy the 8 KiB buy)
+// (y1 / y2: the channel values of primed positions lane / 64 + lane, y'[p] = y[perm[p]])
 template <bool LUTS = true, class LDS = SearchLds>
-__device__ __forceinline__ SearchFrame search_prepare_regs(LDS &L, const float *__restrict__ y, long long src,
-                                                           int o1, int o2, u64 Prow, int lane)
+__device__ __forceinline__ SearchFrame search_prepare_vals(LDS &L, float y1, float y2, int o1, int o2, u64 Prow, int lane)
 {
     SearchFrame S;
     S.o1 = o1;
     S.o2 = o2;
-    const float y1 = y[src * 128 + S.o1], y2 = y[src * 128 + S.o2];   // y'[p] = y[perm[p]]
     L.perm[lane] = (unsigned char)S.o1;
     L.perm[lane + 64] = (unsigned char)S.o2;
     L.w[lane] = __builtin_fabsf(y1);
@@ -124,6 +123,13 @@ __device__ __forceinline__ SearchFrame search_prepare_regs(LDS &L, const float *
     S.d0 = wave_xor64(((S.hm >> lane) & 1) ? Prow : 0ull) ^ S.hp;
     wave_fence();
     return S;
+}
+
+template <bool LUTS = true, class LDS = SearchLds>
+__device__ __forceinline__ SearchFrame search_prepare_regs(LDS &L, const float *__restrict__ y, long long src,
+                                                           int o1, int o2, u64 Prow, int lane)
+{
+    return search_prepare_vals<LUTS>(L, y[src * 128 + o1], y[src * 128 + o2], o1, o2, Prow, lane);
 }
 
 template <bool LUTS = true, class LDS = SearchLds>

@@ -186,6 +186,40 @@ def test_pb_workgroup_kernel_ties(dec, quant):
         dec.set_pb_tuning(**prev)
 
 
+@pytest.mark.parametrize("snr,order,quant", [(2.5, 3, 0.0), (1.0, 3, 0.0), (2.0, 2, 0.0), (1.5, 3, 512.0)])
+def test_pb_front_end_inside_the_first_kernel(dec, snr, order, quant):
+    """With params.reserved bit 0, ldpc_osd_decode runs the OSD front end inside the PB singles kernel (round 4: no workspace
+    between them; a frame of the list replay is then set up from its singles record); by default the front end is a kernel of
+    its own, and ldpc_osd_front + ldpc_osd_search is the third way to the same search: all three agree word for word, on an
+    index list too.  (quant: quantised channel values -- massive ties, the list replay.)"""
+    from short_ldpc_decoding_osd_amd import _lib
+    y, cw = _failures(dec, snr, 2500, seed=int(snr * 10) + 40 + order)
+    if quant:
+        y = (np.round(y * quant) / quant).astype(np.float32)
+    y, cw = y[:700], cw[:700]
+    yd = to_dev(y, dec)
+    outs = []
+    for kw in (dict(), dict(pb_front_inside=True)):
+        aux = torch.zeros((y.shape[0], 4), dtype=torch.int32, device=dec.device)
+        o = dec.osd_decode(yd, order, params=dec.osd_params(order, _lib.OSD_PB, snr_db=snr, aux=aux, **kw))
+        outs.append({k: o[k].clone() for k in ("cw", "metric", "best", "ntep")} | {"aux": aux})
+    aux = torch.zeros((y.shape[0], 4), dtype=torch.int32, device=dec.device)
+    perm, parity, _ = dec.osd_front(yd)
+    o = dec.osd_search(yd, perm, parity, dec.osd_params(order, _lib.OSD_PB, snr_db=snr, aux=aux))
+    outs.append({k: o[k].clone() for k in ("cw", "metric", "best", "ntep")} | {"aux": aux})
+    torch.cuda.synchronize()
+    for other in outs[1:]:
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], other[k]), k
+    # an index list over a larger batch: every third frame, in reverse
+    idx = torch.arange(y.shape[0] - 1, -1, -3, device=dec.device, dtype=torch.int32).contiguous()
+    a = dec.osd_decode(yd, order, index=idx, params=dec.osd_params(order, _lib.OSD_PB, snr_db=snr, pb_front_inside=True))
+    torch.cuda.synchronize()
+    sel = idx.long()
+    for k in ("cw", "metric", "best", "ntep"):
+        assert torch.equal(a[k][: idx.numel()], outs[0][k][sel]), k
+
+
 @pytest.mark.parametrize("tuning", [dict(budget_s=64, budget_m=64, budget=64), dict(budget_s=700, budget_m=700, budget=700),
                                     dict(late_pct=100000, late_div=64, late_min=0)])
 def test_pb_ties_under_schedules(dec, tuning):
