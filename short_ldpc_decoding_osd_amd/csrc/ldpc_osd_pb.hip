@@ -2594,11 +2594,14 @@ __device__ __forceinline__ int coop_scan_chunk(PbCoopLds<NW> &L, CoopRed<NW> &R,
         const unsigned sR = sumbits(L.rk[nrec - 1]);
         if (reason == 0 || sR < sF) { reason = 2; sstop = sR; }
     }
+    // the records that count: all of them without a stop and when the LAST record stops by rule 2 (the records are in visit order,
+    // equal sums included -- counting "sums below the stopping record's" dropped a record that ties with it: found by
+    // tests/tools/pb_long_fuzz.py on quantised channel values); those below the firing sum when rule 1 stops (a record ON that
+    // sum has left the pass above)
     int nbefore = nrec;
-    if (reason) {
+    if (reason == 1) {
         nbefore = 0;
         for (int u = 0; u < nrec; ++u) nbefore += sumbits(L.rk[u]) < sstop;
-        nbefore += reason == 2;
     }
     // positions: the keys below the last record that counts, the keys below the stopping sum; ties (one exchange: 13 + 13 + 1 bits)
     const u64 bk = nbefore > 0 ? L.rk[nbefore - 1] : 0ull;

@@ -220,6 +220,29 @@ def test_pb_front_end_inside_the_first_kernel(dec, snr, order, quant):
         assert torch.equal(a[k][: idx.numel()], outs[0][k][sel]), k
 
 
+@pytest.mark.parametrize("quant,picks", [(1024.0, (293,)), (64.0, (344, 371))])
+def test_pb_two_records_on_one_sum(dec, quant, picks):
+    """Found by tests/tools/pb_long_fuzz.py (round 4): two improvement candidates with EQUAL sums of which the second stops by the
+    success rule.  The workgroup kernel orders equal sums by the visit comparator since round 4 and counted "records with a sum
+    below the stopping record's" -- one short when the record before it ties with it: it returned the earlier record as the
+    winner (TEP count, metric and counters of that one).  The records are in visit order: all of them count."""
+    snr, order = 1.5, 3
+    y, cw = np_oracle.make_frames(dec.code.G, snr, 823, np.random.default_rng(951034177))
+    y = (np.round(y * quant) / quant).astype(np.float32)
+    soft = c_oracle.nms(dec.code.H, y, 10, ALPHA0)
+    _, fail, _ = c_oracle.evaluate(dec.code.H, soft, cw)
+    idx = np.flatnonzero(fail)[list(picks)]
+    for tuning in (dict(), dict(budget_s=64, budget_m=64, budget=64, budget_l=64, budget_xl=64)):
+        prev = dec.set_pb_tuning(**tuning)
+        try:
+            ref = None
+            for path in PATHS:
+                ref = _check(dec, y[idx], cw[idx], order, snr, path, ref)
+            assert (ref["suc2"] >= 6).all() and (ref["stop"] == 2).all()
+        finally:
+            dec.set_pb_tuning(**prev)
+
+
 @pytest.mark.parametrize("tuning", [dict(budget_s=64, budget_m=64, budget=64), dict(budget_s=700, budget_m=700, budget=700),
                                     dict(late_pct=100000, late_div=64, late_min=0)])
 def test_pb_ties_under_schedules(dec, tuning):
