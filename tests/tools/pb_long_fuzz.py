@@ -21,8 +21,9 @@ while time.time() < t_end:
     frames = int(rng.integers(300, 4000))
     seed = int(rng.integers(1 << 30))
     y, cw = np_oracle.make_frames(dec.code.G, snr, frames, np.random.default_rng(seed))
-    if rng.random() < 0.2:
-        q = float(rng.choice([64.0, 1024.0, 65536.0]))
+    q = 0.0
+    if rng.random() < 0.3:
+        q = float(rng.choice([16.0, 64.0, 256.0, 1024.0, 8192.0, 65536.0]))
         y = (np.round(y * q) / q).astype(np.float32)
     soft = c_oracle.nms(dec.code.H, y, 10, ALPHA0)
     _, fail, _ = c_oracle.evaluate(dec.code.H, soft, cw)
@@ -37,10 +38,11 @@ while time.time() < t_end:
                       t3=int(rng.integers(256, 4097)), late_min=int(rng.choice([0, 4608])), late_pct=int(rng.choice([0, 20, 100, 100000])),
                       late_div=int(rng.choice([1, 4, 16, 64])))
     inside = bool(rng.random() < 0.4)
+    path = None if inside or rng.random() < 0.85 else str(rng.choice(["block", "replay"]))
     dec.set_pb_tuning(**tuning) if tuning else dec.set_pb_tuning()
     ref = c_oracle.pb_osd(dec.code.G, y, cw, order, snr)
     aux = torch.zeros((y.shape[0], 4), dtype=torch.int32, device=dec.device)
-    out = dec.osd_decode(to_dev(y, dec), order, params=dec.osd_params(order, _lib.OSD_PB, snr_db=snr, aux=aux, pb_front_inside=inside))
+    out = dec.osd_decode(to_dev(y, dec), order, params=dec.osd_params(order, _lib.OSD_PB, snr_db=snr, aux=aux, pb_front_inside=inside, pb_path=path))
     torch.cuda.synchronize()
     a = aux.cpu().numpy()
     ok = (np.array_equal(out["ntep"].cpu().numpy(), ref["num_teps"]) and np.array_equal(a[:, 3], ref["stop"]) and
@@ -48,7 +50,7 @@ while time.time() < t_end:
           np.array_equal(out["best"].cpu().numpy(), ref["best_index"]) and np.array_equal(words_np(out["cw"]), pack_np(ref["codeword"])) and
           np.array_equal(out["metric"].cpu().numpy(), ref["metric"]))
     if not ok:
-        print("MISMATCH", dict(snr=snr, order=order, frames=frames, seed=seed, tuning=tuning, inside=inside), flush=True)
+        print("MISMATCH", dict(snr=snr, order=order, frames=frames, seed=seed, quant=q, tuning=tuning, inside=inside, path=path), flush=True)
         sys.exit(1)
     total += y.shape[0]; rounds += 1
     if rounds % 20 == 0:
