@@ -4,7 +4,7 @@ Host-side, not on the timed path: the benchmark generates its frames on the devi
 import numpy as np
 
 from . import globalmap as GL
-from .tfrecord import TFRecordWriter, encode_example
+from .tfrecord import TFRecordWriter, encode_example, write_examples
 
 
 def testing_data_generating(code, SNR, max_frame, rng=None):
@@ -37,6 +37,4 @@ def get_tfrecords_example(feature, label):
 def make_tfrecord(data, out_filename):
     """One Example per row (data_generating.py:16-26)."""
     feats, labels = data
-    with TFRecordWriter(out_filename) as wrt:
-        for inx in range(len(labels)):
-            wrt.write(encode_example(feats[inx], labels[inx]))
+    write_examples(out_filename, feats, labels)
