@@ -26,7 +26,10 @@ def _snapshot(pipe):
                 hard=pipe.hard.cpu().numpy().copy(), counters=pipe.counters().cpu().numpy().copy())
 
 
-@pytest.mark.parametrize("algo,order,B", [("conv", 2, 40000), ("pb", 3, 6000), ("fs", 2, 20000)])
+# ("pb", 3, 72000): ~6000 frames per stream search beyond the weight-1 head, more than the 4608 from which the chunk kernel's tail
+# rule is on: every stream counts its own finished frames (control words of the stream's workspace) and hands searches on at
+# moments that depend on the other streams' load
+@pytest.mark.parametrize("algo,order,B", [("conv", 2, 40000), ("pb", 3, 6000), ("fs", 2, 20000), ("pb", 3, 72000)])
 def test_three_streams_one_context(dec, algo, order, B):
     from short_ldpc_decoding_osd_amd import _lib
     from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline
