@@ -26,7 +26,8 @@ def _snapshot(pipe):
 
 
 @pytest.mark.parametrize("algo,order,B,keep_front", [("conv", 2, 20000, True), ("pb", 3, 5000, True), ("fs", 2, 8000, True),
-                                                     ("conv", 2, 8000, False), ("pb", 2, 4000, False)])
+                                                     ("conv", 2, 8000, False), ("pb", 2, 4000, False),
+                                                     ("pb", 3, 72000, False)])      # (long lists: the tail rule's counters are cleared inside the graph)
 def test_pipeline_step_in_a_graph(dec, algo, order, B, keep_front):
     from short_ldpc_decoding_osd_amd import _lib
     from short_ldpc_decoding_osd_amd.pipeline import BatchPipeline
